@@ -1,0 +1,138 @@
+"""Case table shared by the golden generator (make_golden.py) and the tests.
+
+Pure data + tiny helpers; no reference import.  A=256 is the additive-attention hidden size
+hard-coded by the reference assemblies (xnrs/models/full_models/nrms.py:18,34).
+"""
+import numpy as np
+import torch
+
+
+def block_mask(rng, B, N):
+    """(B,N,1) 0/1 mask: row 0 partially masked, last row of the batch fully masked when B>1."""
+    L = rng.integers(1, N + 1, size=(B,))
+    m = (np.arange(N)[None, :] < L[:, None]).astype(np.float32)
+    if B > 1:
+        m[-1] = 0.0
+    return m[..., None].copy()
+
+
+BLOCKS = {
+    # AdditiveAttention (xnrs/models/components/layers.py:40-69)
+    "add_tiny": dict(kind="additive", B=2, N=8, D=32, A=256, mask=True, seed=100),
+    "add_nomask": dict(kind="additive", B=3, N=4, D=16, A=256, mask=False, seed=101),
+    "add_768": dict(kind="additive", B=2, N=50, D=768, A=256, mask=True, seed=102),
+    "add_odd": dict(kind="additive", B=3, N=7, D=20, A=24, mask=True, seed=103),
+    # MultiHeadAttention (layers.py:105-156)
+    "mha_tiny": dict(kind="mha", B=2, N=8, D=32, h=4, mask=True, seed=110),
+    "mha_nomask": dict(kind="mha", B=2, N=5, D=32, h=4, mask=False, seed=111),
+    "mha_300_15": dict(kind="mha", B=3, N=30, D=300, h=15, mask=True, seed=112),
+    "mha_320_16": dict(kind="mha", B=2, N=30, D=320, h=16, mask=True, seed=113),
+    "mha_768_16": dict(kind="mha", B=2, N=50, D=768, h=16, mask=True, seed=114),
+    "mha_user": dict(kind="mha", B=4, N=25, D=256, h=16, mask=True, seed=115),
+    "mha_dk6": dict(kind="mha", B=2, N=9, D=18, h=3, mask=True, seed=116),
+    "mha_s70": dict(kind="mha", B=2, N=70, D=64, h=4, mask=True, seed=117),
+    # MaskedMean (layers.py:19-37)
+    "mean_tiny": dict(kind="mean", B=3, N=8, D=32, seed=120),
+    # DotScoring (scoring.py:6-23)
+    "dot_tiny": dict(kind="dot", B=3, N=5, D=16, normalize=False, seed=130),
+    "dot_norm": dict(kind="dot", B=3, N=5, D=256, normalize=True, seed=131),
+}
+
+ENCODERS = {
+    # TextEncoder (news_encoding.py:8-60): att / pooler / head / bias variants
+    "news_nrms_tiny": dict(tower="news", B=2, N=3, S=8, D=32, h=4, A=256, E=16, att=True, pooler="additive", head=True, bias=True, seed=200),
+    "news_add_head_nobias": dict(tower="news", B=2, N=3, S=8, D=32, h=4, A=256, E=16, att=False, pooler="additive", head=True, bias=False, seed=201),
+    "news_add_nohead": dict(tower="news", B=2, N=3, S=8, D=32, h=4, A=256, E=32, att=False, pooler="additive", head=False, bias=True, seed=202),
+    "news_mean_head": dict(tower="news", B=2, N=3, S=8, D=32, h=4, A=256, E=16, att=False, pooler="mean", head=True, bias=True, seed=203),
+    "news_nrms_300": dict(tower="news", B=2, N=4, S=30, D=300, h=15, A=256, E=256, att=True, pooler="additive", head=True, bias=True, seed=204),
+    "news_nrms_768": dict(tower="news", B=1, N=3, S=50, D=768, h=16, A=256, E=256, att=True, pooler="additive", head=True, bias=True, seed=205),
+    # UserEncoder (user_encoding.py:6-81)
+    "user_nrms": dict(tower="user", B=3, N=25, D=256, h=16, A=256, E=256, att=True, pooler="additive", head=False, bias=True, seed=210),
+    "user_std_head": dict(tower="user", B=3, N=7, D=32, h=4, A=256, E=32, att=False, pooler="additive", head=True, bias=False, seed=211),
+    "user_mean": dict(tower="user", B=3, N=7, D=32, h=4, A=256, E=32, att=False, pooler="mean", head=False, bias=True, seed=212),
+}
+
+MODELS = {
+    "nrms_tiny": dict(model="NRMS", B=3, H=4, C=3, S=8, D=32, h=4, E=16, bias=False, seed=300),
+    "nrms_300": dict(model="NRMS", B=2, H=6, C=5, S=30, D=300, h=15, E=240, bias=False, seed=301, min_len=5),
+    "nrms_shipped": dict(model="NRMS", B=1, H=2, C=2, S=50, D=768, h=16, E=256, bias=False, seed=302, min_len=5),
+    "standard_tiny": dict(model="standard", B=3, H=4, C=3, S=8, D=32, h=4, E=16, bias=False, seed=310),
+    "standard_bias": dict(model="standard", B=2, H=5, C=5, S=12, D=64, h=4, E=32, bias=True, seed=311),
+    "base_tiny": dict(model="base", B=3, H=4, C=3, S=8, D=32, h=4, E=16, bias=False, seed=320),
+    "naml_tiny": dict(model="NAML", B=2, H=4, C=3, S=8, D=32, h=4, E=16, bias=False, seed=330),
+}
+
+LSTUR = dict(model="LSTUR", B=2, H=4, C=3, S=8, D=32, h=4, E=16, bias=False, seed=340)
+
+GRAD = dict(model="NRMS", B=4, H=3, C=3, S=8, D=32, h=4, E=16, bias=False, seed=400,
+            temperature=0.08, lambda_cl=0.1)
+
+
+def model_cfg(c: dict) -> dict:
+    """The flat YAML keys make_model reads (xnrs/models/make_model.py:17-18, nrms.py:12-41,
+    naml.py:12-59), at the case's shape."""
+    return dict(
+        model=c["model"], scoring="dot", total_emb_dim=c["E"], title_emb_dim=c["E"], bias=c["bias"],
+        n_heads=c["h"], d_backbone=c["D"], p_dropout=0.0, cat_emb_dim=16, sub_emb_dim=16,
+        n_categories=19, n_subcategories=300, catg_features=[], text_features=["title_emb"],
+        user_features=[], add_features=[], hist_len=c["H"], seq_len=c["S"],
+    )
+
+
+def theme_labels(themes):
+    """Deterministic stand-in for training.py:414-417 (string themes -> int labels); the label
+    *values* do not matter to the loss, only equality does."""
+    uniq = sorted(set(themes))
+    idx = {t: i for i, t in enumerate(uniq)}
+    return torch.tensor([idx[t] for t in themes])
+
+
+# ----------------------------------------------------------------------------------------------
+# input regeneration (shared by make_golden.py and the tests so both sides see identical bits)
+def block_inputs(c):
+    """-> (x:(B,N,D), m:(B,N,1), u:(B,1,D) or None) for a BLOCKS case."""
+    from xnrs_amd import synth
+    rng = synth.rng_for(c["seed"])
+    B, N, D = c["B"], c["N"], c["D"]
+    x = torch.from_numpy(rng.standard_normal((B, N, D)).astype(np.float32))
+    m = torch.from_numpy(block_mask(rng, B, N))
+    u = None
+    if c["kind"] == "dot":
+        u = torch.from_numpy(rng.standard_normal((B, 1, D)).astype(np.float32))
+    return x, m, u
+
+
+def encoder_inputs(c):
+    """-> (x, m) for an ENCODERS case: news tower (B,N,S,D)/(B,N,S,1); user tower (B,N,D)/(B,N,1)."""
+    from xnrs_amd import synth
+    rng = synth.rng_for(c["seed"])
+    if c["tower"] == "news":
+        return synth.token_block(rng, c["B"], c["N"], c["S"], c["D"], min_len=1, full_pad_prob=0.25)
+    x = torch.from_numpy(rng.standard_normal((c["B"], c["N"], c["D"])).astype(np.float32))
+    m = torch.from_numpy(block_mask(rng, c["B"], c["N"]))
+    return x, m
+
+
+def model_batch(c):
+    from xnrs_amd import synth
+    naml = c["model"] == "NAML"
+    return synth.make_batch(c["seed"], c["B"], c["H"], c["C"], c["S"], c["D"], min_len=c.get("min_len", 1),
+                            abstract=naml, n_categories=19 if naml else 0, n_subcategories=300 if naml else 0)
+
+
+def lstur_inputs(c=None):
+    from xnrs_amd import synth
+    c = c or LSTUR
+    rng = synth.rng_for(c["seed"])
+    x, m = synth.token_block(rng, c["B"], c["H"], c["S"], c["D"])
+    ci = torch.from_numpy(rng.integers(0, 19 + 1, size=(c["B"], c["H"])).astype(np.int32))
+    si = torch.from_numpy(rng.integers(0, 300 + 1, size=(c["B"], c["H"])).astype(np.int32))
+    return x, m, ci, si
+
+
+def infonce_inputs():
+    from xnrs_amd import synth
+    rng = synth.rng_for(GRAD["seed"] + 7)
+    e = torch.from_numpy(rng.standard_normal((8, 16)).astype(np.float32))
+    lab = torch.from_numpy(rng.integers(0, 3, size=(8,)))
+    return e, lab

@@ -1,0 +1,219 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ from the REAL reference implementation.
+
+Runs only in the build container (needs /root/reference); the GPU box never sees the reference.
+The reference's hot-path modules are imported with the recipe of SURVEY.md section 8c (the two package
+``__init__`` files that pull in dotmap/wandb are skipped by pre-seeding ``sys.modules``).
+
+What is stored: ONLY outputs (numpy arrays) + the generator parameters.  Inputs and weights are
+regenerated from PCG64 seeds by ``xnrs_amd.synth`` on every machine, so the fixtures stay small
+and contain no reference source.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+for name, path in [("xnrs", f"{REF}/xnrs"), ("xnrs.models", f"{REF}/xnrs/models")]:
+    mod = types.ModuleType(name)
+    mod.__path__ = [path]
+    sys.modules[name] = mod
+
+from xnrs.models.components import layers, news_encoding, user_encoding, scoring  # noqa: E402
+from xnrs.models.full_models import NRMS, NAML, StandardRec, BaseRec  # noqa: E402
+from xnrs.models.full_models.lstur import LSTURNewsEncoder  # noqa: E402
+from xnrs.models.make_model import make_model  # noqa: E402
+
+# xnrs/training.py imports two absent third-party packages that are not on the arithmetic path
+# (SURVEY.md section 8c recipe 2): give them empty stand-ins so the reference's own InfoNCE
+# (ContrastiveRankingTrainer._compute_contrastive_loss, training.py:433-472) can be called.
+import importlib.machinery  # noqa: E402
+
+for name, attrs in [("omegaconf", {"DictConfig": dict}), ("wandb", {})]:
+    if name not in sys.modules:
+        mod = types.ModuleType(name)
+        mod.__spec__ = importlib.machinery.ModuleSpec(name, None)
+        for k, v in attrs.items():
+            setattr(mod, k, v)
+        sys.modules[name] = mod
+from xnrs.training import ContrastiveRankingTrainer  # noqa: E402
+
+from xnrs_amd import synth  # noqa: E402
+from tests.golden import cases  # noqa: E402
+
+
+def reference_infonce(emb, labels, temperature):
+    """Call the reference's own loss with a bare ``self`` that only carries the temperature."""
+    holder = types.SimpleNamespace(temperature=temperature)
+    return ContrastiveRankingTrainer._compute_contrastive_loss(holder, emb, labels)
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def load(module, seed):
+    shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    sd = synth.fill_state_dict(shapes, seed)
+    module.load_state_dict(sd)
+    module.eval()
+    return module
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def block_cases():
+    out = {}
+    for name, c in cases.BLOCKS.items():
+        D = c["D"]
+        x, m, u = cases.block_inputs(c)
+        kind = c["kind"]
+        with torch.no_grad():
+            if kind == "additive":
+                mod = load(layers.AdditiveAttention(D, c["A"]), c["seed"] + 1)
+                y, a = mod(x, m if c["mask"] else None, return_weights=True)
+                out[f"{name}/y"], out[f"{name}/a"] = npy(y), npy(a)
+            elif kind == "mha":
+                mod = load(layers.MultiHeadAttention(c["h"], D), c["seed"] + 1)
+                out[f"{name}/y"] = npy(mod(x, m if c["mask"] else None))
+            elif kind == "mean":
+                out[f"{name}/y"] = npy(layers.MaskedMean()(x, m))
+            elif kind == "dot":
+                out[f"{name}/y"] = npy(scoring.DotScoring(normalize=c["normalize"])(u, x))
+            else:
+                raise ValueError(kind)
+    return out
+
+
+def encoder_cases():
+    out = {}
+    for name, c in cases.ENCODERS.items():
+        D, E, A = c["D"], c["E"], c["A"]
+        x, m = cases.encoder_inputs(c)
+        att = layers.MultiHeadAttention(c["h"], D) if c["att"] else None
+        pooler = layers.AdditiveAttention(D, A) if c["pooler"] == "additive" else layers.MaskedMean()
+        with torch.no_grad():
+            if c["tower"] == "news":
+                enc = load(news_encoding.TextEncoder(pooler=pooler, p_dropout=0.0, out_features=E, in_features=D,
+                                                     head=c["head"], att=att, bias=c["bias"]), c["seed"] + 1)
+                y, hm = enc((x, m))
+                out[f"{name}/y"], out[f"{name}/hm"] = npy(y), npy(hm)
+            else:
+                enc = load(user_encoding.UserEncoder(pooler=pooler, p_dropout=0.0, emb_dim=D, att=att,
+                                                     head=c["head"], bias=c["bias"]), c["seed"] + 1)
+                if c["pooler"] == "additive":
+                    y, a = enc((x, m), None, return_weights=True)
+                    out[f"{name}/a"] = npy(a)
+                else:
+                    y = enc((x, m))
+                out[f"{name}/y"] = npy(y)
+    return out
+
+
+def model_cases():
+    out = {}
+    for name, c in cases.MODELS.items():
+        cfg = Cfg(cases.model_cfg(c))
+        model = load(make_model(cfg), c["seed"] + 1)
+        batch = cases.model_batch(c)
+        with torch.no_grad():
+            if c["model"] == "NAML":
+                out[f"{name}/r"] = npy(model(batch))
+                out[f"{name}/ue"] = npy(model.get_user_embeddings(batch))
+            else:
+                r, u, cc = model(batch, return_embeddings=True)
+                out[f"{name}/r"], out[f"{name}/u"], out[f"{name}/c"] = npy(r), npy(u), npy(cc)
+                out[f"{name}/ue"] = npy(model.get_user_embeddings(batch))
+    return out
+
+
+def lstur_case():
+    c = cases.LSTUR
+    cfg = Cfg(cases.model_cfg(c))
+    cfg["catg_features"] = ["category_index", "subcategory_index"]
+    enc = load(LSTURNewsEncoder(cfg), c["seed"] + 1)
+    x, m, ci, si = cases.lstur_inputs(c)
+    with torch.no_grad():
+        e, mm = enc((x, m), ci, si)
+    return {"lstur_news/e": npy(e), "lstur_news/m": npy(mm)}
+
+
+def grad_cases():
+    """Loss value + gradients of the reference's train-step loss (training.py:402-472) in eval-mode
+    dropout, computed with the reference's own modules and the reference's own per-row InfoNCE loop."""
+    out = {}
+    c = cases.GRAD
+    cfg = Cfg(cases.model_cfg(c))
+    model = load(make_model(cfg), c["seed"] + 1)
+    batch = cases.model_batch(c)
+    hx, hm = batch["user_features"]["history"]["title_emb"]
+    cx, cm = batch["candidate_features"]["title_emb"]
+    hx.requires_grad_(True)
+    cx.requires_grad_(True)
+    labels = cases.theme_labels(batch["main_theme"])
+    preds = torch.relu(model(batch))
+    loss_rec = torch.nn.functional.mse_loss(preds, batch["targets"])
+    ue = model.get_user_embeddings(batch)
+    loss_cl = reference_infonce(ue, labels, c["temperature"])
+    loss = loss_rec + c["lambda_cl"] * loss_cl
+    loss.backward()
+    out["grad/loss"] = npy(loss)
+    out["grad/loss_rec"] = npy(loss_rec)
+    out["grad/loss_cl"] = npy(loss_cl)
+    out["grad/d_hist_x"] = npy(hx.grad)
+    out["grad/d_cand_x"] = npy(cx.grad)
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            out[f"grad/dW/{k}"] = npy(p.grad)
+    # stand-alone InfoNCE value + gradient (B=8, E=16)
+    e, lab = cases.infonce_inputs()
+    e.requires_grad_(True)
+    l = reference_infonce(e, lab, 0.08)
+    l.backward()
+    out["infonce/loss"], out["infonce/grad"] = npy(l), npy(e.grad)
+    return out
+
+
+def error_cases():
+    """Pin the reference's D % h != 0 failure (layers.py:111,133)."""
+    mod = layers.MultiHeadAttention(16, 300)
+    try:
+        mod(torch.zeros(2, 30, 300), None)
+        return {"err": "none"}
+    except RuntimeError as e:  # noqa: BLE001
+        return {"err": "RuntimeError", "msg": str(e)}
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    groups = {
+        "blocks": block_cases(),
+        "encoders": encoder_cases(),
+        "models": model_cases(),
+        "lstur": lstur_case(),
+        "grads": grad_cases(),
+    }
+    for g, d in groups.items():
+        np.savez_compressed(os.path.join(HERE, f"{g}.npz"), **d)
+        print(g, len(d), "arrays", sum(v.nbytes for v in d.values()), "bytes")
+    meta = {"torch": torch.__version__, "numpy": np.__version__, "errors": error_cases()}
+    with open(os.path.join(HERE, "meta.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print(meta)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,142 @@
+"""Shared test helpers: golden loading, state_dict construction, tolerance checks."""
+import os
+
+import numpy as np
+import torch
+
+from xnrs_amd import synth
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# The parity bar of BASELINE.json north_star: fp32 scores within 1e-4 relative of the reference
+# CPU path.  "Relative" is taken against the tensor's own scale (max |ref|), plus an elementwise
+# rtol, so that near-zero entries of a dot product are not held to an impossible bar.
+RTOL = 1e-4
+
+
+def golden(group):
+    return dict(np.load(os.path.join(GOLDEN_DIR, f"{group}.npz")))
+
+
+def state_for(shapes, seed):
+    return synth.fill_state_dict(shapes, seed)
+
+
+def rel_err(got, ref):
+    got = torch.as_tensor(got, dtype=torch.float64).cpu()
+    ref = torch.as_tensor(ref, dtype=torch.float64).cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    scale = ref.abs().max().item()
+    return (got - ref).abs().max().item() / max(scale, 1e-30)
+
+
+def assert_close(got, ref, tol=RTOL, what=""):
+    e = rel_err(got, ref)
+    assert e <= tol, f"{what}: max|d|/max|ref| = {e:.3e} > {tol:.1e}"
+    return e
+
+
+def linear_shapes(prefix, out_f, in_f, bias=True):
+    s = {f"{prefix}.weight": (out_f, in_f)}
+    if bias:
+        s[f"{prefix}.bias"] = (out_f,)
+    return s
+
+
+def additive_shapes(D, A, prefix=""):
+    p = prefix + "." if prefix else ""
+    return {f"{p}fc1.weight": (A, D), f"{p}fc1.bias": (A,), f"{p}fc2.weight": (1, A), f"{p}fc2.bias": (1,)}
+
+
+def mha_shapes(D, prefix=""):
+    p = prefix + "." if prefix else ""
+    s = {}
+    for n in ("q_linear", "v_linear", "k_linear", "out"):
+        s[f"{p}{n}.weight"] = (D, D)
+        s[f"{p}{n}.bias"] = (D,)
+    return s
+
+
+def encoder_shapes(c):
+    """state_dict key->shape of the reference TextEncoder / UserEncoder for an ENCODERS case
+    (news_encoding.py:20-32, user_encoding.py:17-34)."""
+    D, E, A = c["D"], c["E"], c["A"]
+    s = {"dummy_param": (1,)}
+    if c["att"]:
+        s.update(mha_shapes(D, "att"))
+    if c["pooler"] == "additive":
+        s.update(additive_shapes(D, A, "pooler"))
+    if c["head"]:
+        if c["tower"] == "news":
+            s.update(linear_shapes("head.0", E, D, c["bias"]))
+            s.update(linear_shapes("head.2", E, E, c["bias"]))
+        else:
+            s.update(linear_shapes("head.0", D, D, c["bias"]))
+            s.update(linear_shapes("head.2", D, D, c["bias"]))
+    return s
+
+
+def model_shapes(c):
+    """state_dict key->shape for a MODELS case (nrms.py:11-47, standard_model.py:8-37,
+    base_model.py:10-38, naml.py:9-59)."""
+    D, E, A = c["D"], c["E"], 256
+    s = {}
+    mdl = c["model"]
+    if mdl in ("NRMS", "standard", "base"):
+        s["news_encoder.dummy_param"] = (1,)
+        s["user_encoder.dummy_param"] = (1,)
+        nbias = True if mdl == "NRMS" else c["bias"]
+        if mdl == "NRMS":
+            s.update(mha_shapes(D, "news_encoder.att"))
+            s.update(mha_shapes(E, "user_encoder.att"))
+        s.update(additive_shapes(D, A, "news_encoder.pooler"))
+        s.update(linear_shapes("news_encoder.head.0", E, D, nbias))
+        s.update(linear_shapes("news_encoder.head.2", E, E, nbias))
+        s.update(additive_shapes(E, A, "user_encoder.pooler"))
+        if mdl == "standard":
+            s.update(linear_shapes("user_encoder.head.0", E, E, c["bias"]))
+            s.update(linear_shapes("user_encoder.head.2", E, E, c["bias"]))
+    elif mdl == "NAML":
+        for enc in ("title_encoder", "body_encoder"):
+            s[f"{enc}.dummy_param"] = (1,)
+            s.update(additive_shapes(D, A, f"{enc}.pooler"))
+            s.update(linear_shapes(f"{enc}.head.0", E, D, True))
+            s.update(linear_shapes(f"{enc}.head.2", E, E, True))
+        s["cat_embedder.weight"] = (19 + 1, 16)
+        s.update(linear_shapes("cat_fc", E, 16))
+        s["subcat_embedder.weight"] = (300 + 1, 16)
+        s.update(linear_shapes("subcat_fc", E, 16))
+        s.update(additive_shapes(E, A, "feature_pooler"))
+        s.update(additive_shapes(E, A, "user_encoder"))
+    elif mdl == "LSTUR":  # news encoder only (lstur.py:162-189); pooler hidden = title_emb_dim
+        s["title_encoder.dummy_param"] = (1,)
+        s.update(additive_shapes(D, E, "title_encoder.pooler"))
+        s.update(linear_shapes("title_encoder.head.0", E, D, c["bias"]))
+        s.update(linear_shapes("title_encoder.head.2", E, E, c["bias"]))
+        s["cat_embedder.weight"] = (19 + 1, 16)
+        s["subcat_embedder.weight"] = (300 + 1, 16)
+    else:
+        raise ValueError(mdl)
+    return s
+
+
+def assert_grads_close(grads, g, tol, prefix="grad/dW/"):
+    """Compare a dict of parameter grads with the golden ones.  Gradients that are analytically
+    zero (e.g. the key bias: softmax is invariant to a per-row constant) are pure rounding noise
+    in both implementations, so every tensor is held to ``tol`` relative to
+    max(its own scale, 1e-3 * the largest gradient in the model)."""
+    import numpy as np
+    gmax = max(float(np.abs(v).max()) for k, v in g.items() if k.startswith(prefix))
+    n = 0
+    for k, got in grads.items():
+        key = prefix + k
+        if key not in g:
+            continue
+        ref = torch.as_tensor(g[key], dtype=torch.float64)
+        got = torch.as_tensor(got, dtype=torch.float64).cpu()
+        assert got.shape == ref.shape, (k, got.shape, ref.shape)
+        scale = max(ref.abs().max().item(), 1e-3 * gmax)
+        e = (got - ref).abs().max().item() / scale
+        assert e <= tol, f"{k}: {e:.3e} > {tol:.1e}"
+        n += 1
+    return n

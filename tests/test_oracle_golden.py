@@ -1,0 +1,150 @@
+"""CPU: the oracle (oracle/xnrs_oracle.py) against the golden vectors recorded from the REAL
+reference (tests/golden/make_golden.py).  This is the pin that lets the oracle stand in for the
+reference on the GPU box, where /root/reference does not exist."""
+import json
+import os
+
+import pytest
+import torch
+
+from oracle import xnrs_oracle as O
+from tests import helpers as H
+from tests.golden import cases
+
+TOL = 2e-6  # oracle and reference are both torch-CPU fp32: agree to rounding noise
+
+
+@pytest.mark.parametrize("name", sorted(cases.BLOCKS))
+def test_blocks(name):
+    g = H.golden("blocks")
+    c = cases.BLOCKS[name]
+    x, m, u = cases.block_inputs(c)
+    D = c["D"]
+    if c["kind"] == "additive":
+        sd = H.state_for(H.additive_shapes(D, c["A"]), c["seed"] + 1)
+        y, a = O.additive_attention(x, m if c["mask"] else None, sd, return_weights=True)
+        H.assert_close(y, g[f"{name}/y"], TOL, name)
+        H.assert_close(a, g[f"{name}/a"], TOL, name)
+    elif c["kind"] == "mha":
+        sd = H.state_for(H.mha_shapes(D), c["seed"] + 1)
+        H.assert_close(O.multi_head_attention(x, m if c["mask"] else None, sd, c["h"]), g[f"{name}/y"], TOL, name)
+    elif c["kind"] == "mean":
+        H.assert_close(O.masked_mean(x, m), g[f"{name}/y"], TOL, name)
+    elif c["kind"] == "dot":
+        H.assert_close(O.dot_scoring(u, x, c["normalize"]), g[f"{name}/y"], TOL, name)
+
+
+@pytest.mark.parametrize("name", sorted(cases.ENCODERS))
+def test_encoders(name):
+    g = H.golden("encoders")
+    c = cases.ENCODERS[name]
+    x, m = cases.encoder_inputs(c)
+    sd = H.state_for(H.encoder_shapes(c), c["seed"] + 1)
+    if c["tower"] == "news":
+        y, hm = O.text_encoder(x, m, sd, c["h"])
+        H.assert_close(y, g[f"{name}/y"], TOL, name)
+        assert torch.equal(hm, torch.from_numpy(g[f"{name}/hm"]))
+    else:
+        if c["pooler"] == "additive":
+            y, a = O.user_encoder(x, m, sd, c["h"], return_weights=True)
+            H.assert_close(a, g[f"{name}/a"], TOL, name)
+        else:
+            y = O.user_encoder(x, m, sd, c["h"])
+        H.assert_close(y, g[f"{name}/y"], TOL, name)
+
+
+@pytest.mark.parametrize("name", sorted(cases.MODELS))
+def test_models(name):
+    g = H.golden("models")
+    c = cases.MODELS[name]
+    sd = H.state_for(H.model_shapes(c), c["seed"] + 1)
+    batch = cases.model_batch(c)
+    if c["model"] == "NAML":
+        H.assert_close(O.naml_forward(batch, sd), g[f"{name}/r"], TOL, name)
+        H.assert_close(O.naml_user_embeddings(batch, sd), g[f"{name}/ue"], TOL, name)
+        return
+    hist = batch["user_features"]["history"]["title_emb"]
+    cand = batch["candidate_features"]["title_emb"]
+    r, u, cc = O.parent_forward(hist, cand, sd, c["h"], return_embeddings=True)
+    H.assert_close(r, g[f"{name}/r"], TOL, name)
+    H.assert_close(u, g[f"{name}/u"], TOL, name)
+    H.assert_close(cc, g[f"{name}/c"], TOL, name)
+    H.assert_close(O.parent_user_embeddings(hist, sd, c["h"]), g[f"{name}/ue"], TOL, name)
+
+
+def test_lstur_news_encoder():
+    g = H.golden("lstur")
+    c = cases.LSTUR
+    sd = H.state_for(H.model_shapes(c), c["seed"] + 1)
+    x, m, ci, si = cases.lstur_inputs(c)
+    e, mm = O.lstur_news_encoder((x, m), ci, si, sd)
+    H.assert_close(e, g["lstur_news/e"], TOL)
+    assert torch.equal(mm, torch.from_numpy(g["lstur_news/m"]))
+
+
+def test_infonce_value_and_grad():
+    g = H.golden("grads")
+    e, lab = cases.infonce_inputs()
+    e.requires_grad_(True)
+    l = O.contrastive_loss(e, lab, 0.08)
+    l.backward()
+    H.assert_close(l, g["infonce/loss"], 1e-5)
+    H.assert_close(e.grad, g["infonce/grad"], 1e-5)
+    l2 = O.contrastive_loss_loop(e.detach(), lab, 0.08)
+    H.assert_close(l2, g["infonce/loss"], 1e-5)
+
+
+def test_train_step_loss_and_grads():
+    g = H.golden("grads")
+    c = cases.GRAD
+    sd = H.state_for(H.model_shapes(c), c["seed"] + 1)
+    sd = {k: v.clone().requires_grad_(not k.endswith("dummy_param")) for k, v in sd.items()}
+    batch = cases.model_batch(c)
+    hx, hm = batch["user_features"]["history"]["title_emb"]
+    cx, cm = batch["candidate_features"]["title_emb"]
+    hx.requires_grad_(True)
+    cx.requires_grad_(True)
+    labels = cases.theme_labels(batch["main_theme"])
+    loss, lrec, lcl = O.train_step_loss(batch, sd, c["h"], labels, c["temperature"], c["lambda_cl"])
+    loss.backward()
+    H.assert_close(loss, g["grad/loss"], 1e-5)
+    H.assert_close(lrec, g["grad/loss_rec"], 1e-5)
+    H.assert_close(lcl, g["grad/loss_cl"], 1e-5)
+    H.assert_close(hx.grad, g["grad/d_hist_x"], 2e-5)
+    H.assert_close(cx.grad, g["grad/d_cand_x"], 2e-5)
+    n = H.assert_grads_close({k: v.grad for k, v in sd.items() if v.grad is not None}, g, 5e-5)
+    assert n >= 28
+
+
+def test_quirks_pinned():
+    """The parity-critical quirks of SURVEY.md finding 4, checked on the oracle."""
+    torch.manual_seed(0)
+    D, h, S = 32, 4, 8
+    sd = H.state_for(H.mha_shapes(D), 7)
+    x = torch.randn(1, S, D)
+    m = torch.ones(1, S, 1)
+    m[0, 5:] = 0
+    y0 = O.multi_head_attention(x, m, sd, h)
+    x2 = x.clone()
+    x2[0, 5:] += 1.0  # perturb ONLY masked token positions
+    y1 = O.multi_head_attention(x2, m, sd, h)
+    assert (y0[0, :5] - y1[0, :5]).abs().max() > 1e-3, "row mask: masked keys must still influence valid rows"
+    # additive attention: all-masked -> weights exactly 0 -> pooled vector exactly 0
+    asd = H.state_for(H.additive_shapes(D, 256), 8)
+    out, a = O.additive_attention(x, torch.zeros(1, S, 1), asd, return_weights=True)
+    assert a.abs().max() == 0 and out.abs().max() == 0
+    # head-bias leak: fully padded news -> y = W4 relu(b3) + b4 != 0
+    c = cases.ENCODERS["news_nrms_tiny"]
+    esd = H.state_for(H.encoder_shapes(c), 9)
+    xx = torch.zeros(1, 1, c["S"], c["D"])
+    y, hm = O.text_encoder(xx, torch.zeros(1, 1, c["S"], 1), esd, c["h"])
+    assert y.abs().max() > 1e-3 and hm.item() == 0.0
+
+
+def test_d_mod_h_error_matches_reference():
+    meta = json.load(open(os.path.join(H.GOLDEN_DIR, "meta.json")))
+    assert meta["errors"]["err"] == "RuntimeError"
+    sd = H.state_for(H.mha_shapes(300), 1)
+    with pytest.raises(RuntimeError) as ei:
+        O.multi_head_attention(torch.zeros(2, 30, 300), None, sd, 16)
+    assert str(ei.value) == meta["errors"]["msg"]
