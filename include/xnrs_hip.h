@@ -1,0 +1,131 @@
+/*
+ * xnrs_hip.h -- C ABI of libxnrs_hip.so: the MI355X (gfx950) implementation of the xnrs
+ * user-news scoring hot path (news encode -> user encode -> dot-product score).
+ *
+ * The reference (tan9zj/xnrs) is 100% Python/PyTorch and defines NO FFI of its own; its interface
+ * for this path is the `xnrs.models.components` module API.  Every entry point below therefore
+ * cites the reference *method* it replaces (file:line relative to the reference repo root); the
+ * Python host side (xnrs_amd/models/...) keeps the reference's class names, constructor
+ * signatures and state_dict keys and binds these symbols with ctypes.
+ *
+ * Conventions
+ *   - all tensors are contiguous row-major fp32 DEVICE pointers unless stated; masks are fp32 0/1
+ *     exactly like the reference (news_encoding.py:34-50); ids are int32 device pointers.
+ *   - nn.Linear weights keep the reference layout W[out][in] (K-contiguous), bias[out] or NULL.
+ *   - no allocation, no global state, no host sync: the caller supplies the workspace (size from
+ *     the *_workspace_bytes query) and a hipStream_t (as void*; NULL = default stream).  Safe to
+ *     capture into a hipGraph.
+ *   - return value: 0 = ok; >0 = hipError_t of the failed launch; <0 = XNRS_E* argument error.
+ *     xnrs_error_string() explains either.
+ */
+#ifndef XNRS_HIP_H
+#define XNRS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XNRS_ABI_VERSION 1
+
+#define XNRS_OK 0
+#define XNRS_EINVAL (-1)     /* bad shape / NULL pointer */
+#define XNRS_EHEADS (-2)     /* d_model % n_heads != 0 (reference raises RuntimeError, layers.py:111,133) */
+#define XNRS_EWORKSPACE (-3) /* workspace too small */
+#define XNRS_EUNSUPPORTED (-4)
+
+/* activation fused into a Linear's epilogue */
+#define XNRS_ACT_NONE 0
+#define XNRS_ACT_RELU 1
+#define XNRS_ACT_TANH 2
+
+/* pooler kinds */
+#define XNRS_POOL_ADDITIVE 0 /* layers.AdditiveAttention (layers.py:40-69) */
+#define XNRS_POOL_MEAN 1     /* layers.MaskedMean        (layers.py:19-37) */
+
+/* layers.MultiHeadAttention parameters (layers.py:106-118): four Linear(D,D) */
+typedef struct {
+  const float *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo;
+  int32_t n_heads;
+  int32_t scaled;   /* 1: scores / sqrt(d_k) (layers.py:139-140) */
+  float dropout_p;  /* attention-probability dropout (layers.py:117,148); 0 in eval mode */
+  uint64_t seed;    /* counter-based RNG seed for dropout; ignored when dropout_p == 0 */
+} xnrs_mha_params;
+
+/* layers.AdditiveAttention parameters (layers.py:42-45): fc1 Linear(D,A), fc2 Linear(A,1) */
+typedef struct {
+  const float *w1, *b1, *w2, *b2;
+  int32_t hidden; /* A */
+} xnrs_additive_params;
+
+/* nn.Sequential(Linear(in,out), ReLU, Linear(out,out)) head
+ * (news_encoding.py:25-31, user_encoding.py:30-34); biases may be NULL (bias=False) */
+typedef struct {
+  const float *w0, *b0, *w2, *b2;
+  int32_t out_features;
+} xnrs_head_params;
+
+int32_t xnrs_abi_version(void);
+const char *xnrs_error_string(int32_t code);
+
+/* ---- nn.Linear (layers.py:60,128-130,154; news_encoding.py:27-31) --------------------------
+ * y[M,N] = act(x[M,K] . w[N,K]^T + bias[N]).  If gather_ids != NULL, logical row m of x is row
+ * gather_ids[m / gather_S] * gather_S + m % gather_S of the table `x` (device-resident news-token
+ * table [n_news,S,D] + id gather fused into the load: SURVEY.md section 8 a0). */
+int32_t xnrs_linear_fwd(const float *x, const int32_t *gather_ids, int32_t gather_S, const float *w,
+                        const float *bias, float *y, int64_t M, int32_t N, int32_t K, int32_t act,
+                        void *stream);
+
+/* ---- layers.MultiHeadAttention.forward (layers.py:120-156) ---------------------------------
+ * x:(B,S,D), m:(B,S) fp32 0/1 or NULL -> y:(B,S,D).  Row-mask semantics of layers.py:142-144. */
+size_t xnrs_mha_workspace_bytes(int64_t B, int32_t S, int32_t D);
+int32_t xnrs_mha_fwd(const float *x, const float *m, const xnrs_mha_params *p, float *y, int64_t B,
+                     int32_t S, int32_t D, void *ws, size_t ws_bytes, void *stream);
+
+/* ---- layers.AdditiveAttention.forward (layers.py:47-69) ------------------------------------
+ * x:(B,N,D), m:(B,N) or NULL -> y:(B,D); a_out:(B,N) optional attention weights (return_weights). */
+size_t xnrs_additive_workspace_bytes(int64_t B, int32_t N, int32_t D, int32_t A);
+int32_t xnrs_additive_attention_fwd(const float *x, const float *m, const xnrs_additive_params *p,
+                                    float *y, float *a_out, int64_t B, int32_t N, int32_t D, void *ws,
+                                    size_t ws_bytes, void *stream);
+
+/* ---- layers.MaskedMean.forward (layers.py:26-37) : y = sum(x*m)/(sum(m)+1e-8) -------------- */
+int32_t xnrs_masked_mean_fwd(const float *x, const float *m, float *y, int64_t B, int32_t N, int32_t D,
+                             void *stream);
+
+/* ---- xnrs.utils.collaps_mask (utils.py:74-75): hm = clamp(sum_S m, 0, 1) ------------------- */
+int32_t xnrs_collapse_mask(const float *m, float *hm, int64_t n_rows, int32_t S, void *stream);
+
+/* ---- TextEncoder.forward (news_encoding.py:34-60) -------------------------------------------
+ * x:(n_news,S,D) [or table + ids, see xnrs_linear_fwd], m:(n_news,S) -> y:(n_news,E'), hm:(n_news).
+ * att == NULL: no self-attention stage; head == NULL: y is the pooled D-vector (E' = D).
+ * If ids != NULL, x and m are the TABLE ([n_table,S,D], [n_table,S]) and n_news = len(ids).
+ * `chunk` = news per internal pass (bounds the workspace; 0 = library default). */
+size_t xnrs_text_encoder_workspace_bytes(int64_t n_news, int32_t S, int32_t D, int32_t A, int32_t E,
+                                         int32_t has_att, int32_t pool_kind, int32_t has_head,
+                                         int64_t chunk);
+int32_t xnrs_text_encoder_fwd(const float *x, const float *m, const int32_t *ids, int64_t n_news,
+                              int32_t S, int32_t D, const xnrs_mha_params *att, int32_t pool_kind,
+                              const xnrs_additive_params *pool, const xnrs_head_params *head, float *y,
+                              float *hm, int64_t chunk, void *ws, size_t ws_bytes, void *stream);
+
+/* ---- UserEncoder.forward (user_encoding.py:50-81) -------------------------------------------
+ * x:(B,H,E), m:(B,H) -> y:(B,E) [, a_out:(B,H) when the pooler is additive and a_out != NULL]. */
+size_t xnrs_user_encoder_workspace_bytes(int64_t B, int32_t H, int32_t E, int32_t A, int32_t has_att,
+                                         int32_t pool_kind, int32_t has_head);
+int32_t xnrs_user_encoder_fwd(const float *x, const float *m, int64_t B, int32_t H, int32_t E,
+                              const xnrs_mha_params *att, int32_t pool_kind,
+                              const xnrs_additive_params *pool, const xnrs_head_params *head, float *y,
+                              float *a_out, void *ws, size_t ws_bytes, void *stream);
+
+/* ---- DotScoring.forward (scoring.py:12-23) --------------------------------------------------
+ * u:(B,E), c:(B,C,E) -> r:(B,C); normalize != 0 applies the L2 normalisation of scoring.py:20-22. */
+int32_t xnrs_dot_scoring_fwd(const float *u, const float *c, float *r, int64_t B, int32_t C, int32_t E,
+                             int32_t normalize, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XNRS_HIP_H */

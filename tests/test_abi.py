@@ -1,0 +1,96 @@
+"""CPU: the C-ABI library loads and exports every symbol include/xnrs_hip.h declares; host-side
+logic that needs no GPU (state_dict contract, factory errors, loud failure without a device)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from tests import helpers as H
+from tests.golden import cases
+from xnrs_amd import hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "xnrs_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(xnrs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    syms = header_symbols()
+    assert len(syms) >= 14
+    assert sorted(hip.SYMBOLS) == syms, "xnrs_amd/hip.py SYMBOLS out of sync with include/xnrs_hip.h"
+    l = ctypes.CDLL(hip.LIB_PATH)
+    for s in syms:
+        assert hasattr(l, s), f"libxnrs_hip.so does not export {s}"
+
+
+def test_abi_version_and_error_strings():
+    l = hip.lib()
+    assert l.xnrs_abi_version() == 1
+    assert b"divisible" in l.xnrs_error_string(-2)
+    assert l.xnrs_error_string(0) == b"ok"
+
+
+def test_workspace_queries_are_pure_host_calls():
+    l = hip.lib()
+    n = l.xnrs_text_encoder_workspace_bytes(28160, 50, 768, 256, 256, 1, 0, 1, 0)
+    assert 5e8 < n < 2e9  # chunked: ~64k rows per pass, not 28160*50 rows
+    assert l.xnrs_text_encoder_workspace_bytes(10, 50, 768, 256, 256, 0, 1, 0, 0) == 0  # mean pool, no head
+    assert l.xnrs_mha_workspace_bytes(4, 30, 300) >= 4 * 30 * 300 * 4 * 4
+
+
+@pytest.mark.parametrize("name", sorted(cases.MODELS))
+def test_state_dict_contract(name):
+    """Key names and tensor shapes are part of the drop-in contract."""
+    from xnrs_amd.models import make_model
+    c = cases.MODELS[name]
+    m = make_model(Cfg(cases.model_cfg(c)))
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert got == {k: tuple(v) for k, v in H.model_shapes(c).items()}
+
+
+def test_nrms_param_count_matches_reference():
+    from xnrs_amd.models import make_model
+    cfg = Cfg(cases.model_cfg(dict(model="NRMS", E=256, bias=False, h=16, D=768, H=25, S=50)))
+    m = make_model(cfg)
+    assert sum(p.numel() for p in m.parameters()) == 3_151_364
+    keys = list(m.state_dict().keys())
+    # registration order of the reference MHA: q, v, k, out
+    assert keys[1:9:2] == [f"news_encoder.att.{n}.weight" for n in ("q_linear", "v_linear", "k_linear", "out")]
+
+
+def test_factory_errors():
+    from xnrs_amd.models import make_model
+    base = cases.model_cfg(cases.MODELS["nrms_tiny"])
+    with pytest.raises(ValueError):
+        make_model(Cfg({**base, "scoring": "nonlin"}))
+    with pytest.raises(ValueError):
+        make_model(Cfg({**base, "model": "nope"}))
+    with pytest.raises(NotImplementedError):
+        make_model(Cfg({**base, "model": "CAUM"}))
+
+
+def test_no_silent_cpu_fallback():
+    """Without a HIP device the product path must raise, never compute on the CPU."""
+    from xnrs_amd.models import make_model
+    c = cases.MODELS["nrms_tiny"]
+    m = make_model(Cfg(cases.model_cfg(c))).eval()
+    with torch.no_grad(), pytest.raises(hip.XnrsHipError):
+        m(cases.model_batch(c))
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "xnrs_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("SURVEY", ""), f"{f} mentions the oracle"

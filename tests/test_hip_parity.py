@@ -1,0 +1,204 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs and against the committed golden vectors recorded from the real reference.
+
+Tolerance: BASELINE.json north_star -- fp32 scores within 1e-4 relative of the reference CPU path
+(tests/helpers.py RTOL; "relative" = max|d| / max|ref| per tensor)."""
+import pytest
+import torch
+
+from oracle import xnrs_oracle as O
+from tests import helpers as H
+from tests.golden import cases
+from xnrs_amd import synth
+from xnrs_amd.models import make_model
+from xnrs_amd.models.components import layers, news_encoding, user_encoding, scoring
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def load(module, seed):
+    shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    sd = synth.fill_state_dict(shapes, seed)
+    module.load_state_dict(sd)
+    module.eval()
+    return module.to(DEV), sd
+
+
+@pytest.mark.parametrize("name", sorted(cases.BLOCKS))
+def test_blocks(name):
+    g = H.golden("blocks")
+    c = cases.BLOCKS[name]
+    x, m, u = cases.block_inputs(c)
+    D = c["D"]
+    with torch.no_grad():
+        if c["kind"] == "additive":
+            mod, sd = load(layers.AdditiveAttention(D, c["A"]), c["seed"] + 1)
+            y, a = mod(x.to(DEV), m.to(DEV) if c["mask"] else None, return_weights=True)
+            yo, ao = O.additive_attention(x, m if c["mask"] else None, sd, return_weights=True)
+            H.assert_close(y, yo, what=name + " vs oracle")
+            H.assert_close(a, ao, what=name + " weights vs oracle")
+            H.assert_close(y, g[f"{name}/y"], what=name + " vs golden")
+            H.assert_close(a, g[f"{name}/a"], what=name + " weights vs golden")
+            y1 = mod(x.to(DEV), m.to(DEV) if c["mask"] else None)
+            assert torch.equal(y1, y)
+        elif c["kind"] == "mha":
+            mod, sd = load(layers.MultiHeadAttention(c["h"], D), c["seed"] + 1)
+            y = mod(x.to(DEV), m.to(DEV) if c["mask"] else None)
+            H.assert_close(y, O.multi_head_attention(x, m if c["mask"] else None, sd, c["h"]), what=name + " vs oracle")
+            H.assert_close(y, g[f"{name}/y"], what=name + " vs golden")
+        elif c["kind"] == "mean":
+            y = layers.MaskedMean()(x.to(DEV), m.to(DEV))
+            H.assert_close(y, g[f"{name}/y"], what=name)
+        elif c["kind"] == "dot":
+            y = scoring.DotScoring(normalize=c["normalize"])(u.to(DEV), x.to(DEV))
+            H.assert_close(y, g[f"{name}/y"], what=name)
+
+
+@pytest.mark.parametrize("name", sorted(cases.ENCODERS))
+def test_encoders(name):
+    g = H.golden("encoders")
+    c = cases.ENCODERS[name]
+    x, m = cases.encoder_inputs(c)
+    D, E, A = c["D"], c["E"], c["A"]
+    att = layers.MultiHeadAttention(c["h"], D) if c["att"] else None
+    pooler = layers.AdditiveAttention(D, A) if c["pooler"] == "additive" else layers.MaskedMean()
+    with torch.no_grad():
+        if c["tower"] == "news":
+            enc, sd = load(news_encoding.TextEncoder(pooler=pooler, p_dropout=0.0, out_features=E, in_features=D,
+                                                     head=c["head"], att=att, bias=c["bias"]), c["seed"] + 1)
+            y, hm = enc((x, m))  # CPU inputs: the encoder moves them itself like the reference
+            assert y.is_cuda and y.shape == (c["B"], c["N"], E) and hm.shape == (c["B"], c["N"], 1)
+            H.assert_close(y, g[f"{name}/y"], what=name)
+            assert torch.equal(hm.cpu(), torch.from_numpy(g[f"{name}/hm"]))
+        else:
+            enc, sd = load(user_encoding.UserEncoder(pooler=pooler, p_dropout=0.0, emb_dim=D, att=att,
+                                                     head=c["head"], bias=c["bias"]), c["seed"] + 1)
+            if c["pooler"] == "additive":
+                y, a = enc((x, m), None, return_weights=True)
+                H.assert_close(a, g[f"{name}/a"], what=name)
+            else:
+                y = enc((x, m))
+            H.assert_close(y, g[f"{name}/y"], what=name)
+
+
+@pytest.mark.parametrize("name", sorted(cases.MODELS))
+def test_models(name):
+    g = H.golden("models")
+    c = cases.MODELS[name]
+    model, sd = load(make_model(Cfg(cases.model_cfg(c))), c["seed"] + 1)
+    assert sorted(model.state_dict().keys()) == sorted(H.model_shapes(c).keys())
+    batch = cases.model_batch(c)
+    with torch.no_grad():
+        if c["model"] == "NAML":
+            H.assert_close(model(batch), g[f"{name}/r"], what=name)
+            ue = model.get_user_embeddings(batch)
+            assert ue.dim() == 3
+            H.assert_close(ue, g[f"{name}/ue"], what=name)
+            return
+        r, u, cc = model(batch, return_embeddings=True)
+        H.assert_close(r, g[f"{name}/r"], what=name + " scores")
+        H.assert_close(u, g[f"{name}/u"], what=name + " user")
+        H.assert_close(cc, g[f"{name}/c"], what=name + " cand")
+        H.assert_close(model.get_user_embeddings(batch), g[f"{name}/ue"], what=name + " ue")
+        # oracle on the same inputs
+        hist = batch["user_features"]["history"]["title_emb"]
+        cand = batch["candidate_features"]["title_emb"]
+        H.assert_close(r, O.parent_forward(hist, cand, sd, c["h"]), what=name + " vs oracle")
+
+
+def test_lstur_news_encoder():
+    from xnrs_amd.models.full_models import LSTURNewsEncoder
+    g = H.golden("lstur")
+    c = cases.LSTUR
+    cfg = Cfg(cases.model_cfg(c))
+    cfg["catg_features"] = ["category_index", "subcategory_index"]
+    enc, sd = load(LSTURNewsEncoder(cfg), c["seed"] + 1)
+    x, m, ci, si = cases.lstur_inputs(c)
+    with torch.no_grad():
+        e, mm = enc((x, m), ci, si)
+    H.assert_close(e, g["lstur_news/e"])
+    assert torch.equal(mm.cpu(), torch.from_numpy(g["lstur_news/m"]))
+
+
+def test_quirks_on_device():
+    """Row mask, a==0 on all-masked, head-bias leak (SURVEY.md finding 4) on the HIP path."""
+    D, h, S = 32, 4, 8
+    att, sd = load(layers.MultiHeadAttention(h, D), 7)
+    torch.manual_seed(0)
+    x = torch.randn(1, S, D)
+    m = torch.ones(1, S, 1)
+    m[0, 5:] = 0
+    with torch.no_grad():
+        y0 = att(x.to(DEV), m.to(DEV))
+        x2 = x.clone()
+        x2[0, 5:] += 1.0
+        y1 = att(x2.to(DEV), m.to(DEV))
+        assert (y0[0, :5] - y1[0, :5]).abs().max() > 1e-3
+        H.assert_close(y1, O.multi_head_attention(x2, m, sd, h))
+        pool, psd = load(layers.AdditiveAttention(D, 256), 8)
+        out, a = pool(x.to(DEV), torch.zeros(1, S, 1, device=DEV), return_weights=True)
+        assert a.abs().max() == 0 and out.abs().max() == 0
+        c = cases.ENCODERS["news_nrms_tiny"]
+        enc, esd = load(news_encoding.TextEncoder(pooler=layers.AdditiveAttention(c["D"], 256), p_dropout=0.0,
+                                                  out_features=c["E"], in_features=c["D"],
+                                                  att=layers.MultiHeadAttention(c["h"], c["D"])), 9)
+        y, hm = enc((torch.zeros(1, 1, c["S"], c["D"]), torch.zeros(1, 1, c["S"], 1)))
+        yo, _ = O.text_encoder(torch.zeros(1, 1, c["S"], c["D"]), torch.zeros(1, 1, c["S"], 1), esd, c["h"])
+        assert y.abs().max() > 1e-3 and hm.item() == 0.0
+        H.assert_close(y, yo)
+
+
+def test_d_mod_h_raises_like_reference():
+    att = layers.MultiHeadAttention(16, 300).to(DEV)
+    with torch.no_grad(), pytest.raises(RuntimeError):
+        att(torch.zeros(2, 30, 300, device=DEV), None)
+
+
+def test_gather_matches_materialised():
+    """forward_ids(table, ids) == forward((table[ids], mask[ids]))  (SURVEY.md section 8 a0)."""
+    c = cases.ENCODERS["news_nrms_300"]
+    D, E, S = c["D"], c["E"], c["S"]
+    enc, sd = load(news_encoding.TextEncoder(pooler=layers.AdditiveAttention(D, 256), p_dropout=0.0, out_features=E,
+                                             in_features=D, att=layers.MultiHeadAttention(c["h"], D)), 21)
+    rng = synth.rng_for(22)
+    tx, tm = synth.token_block(rng, 1, 40, S, D, min_len=3)
+    tx, tm = tx[0].to(DEV), tm[0].to(DEV)
+    ids = torch.from_numpy(rng.integers(0, 40, size=(3, 7)).astype("int64")).to(DEV)
+    with torch.no_grad():
+        y1, hm1 = enc.forward_ids(tx, tm, ids)
+        y2, hm2 = enc((tx[ids], tm[ids]))
+    assert torch.equal(y1, y2) and torch.equal(hm1, hm2)
+    for att_on in (False,):
+        enc2, _ = load(news_encoding.TextEncoder(pooler=layers.AdditiveAttention(D, 256), p_dropout=0.0,
+                                                 out_features=E, in_features=D, att=None), 23)
+        with torch.no_grad():
+            y1, _ = enc2.forward_ids(tx, tm, ids)
+            y2, _ = enc2((tx[ids], tm[ids]))
+        assert torch.equal(y1, y2)
+
+
+def test_empty_and_ragged():
+    """Empty batch and S not a multiple of anything convenient."""
+    enc, sd = load(news_encoding.TextEncoder(pooler=layers.AdditiveAttention(20, 24), p_dropout=0.0, out_features=12,
+                                             in_features=20, att=layers.MultiHeadAttention(5, 20)), 31)
+    with torch.no_grad():
+        y, hm = enc((torch.zeros(0, 3, 7, 20), torch.zeros(0, 3, 7, 1)))
+        assert y.shape == (0, 3, 12) and hm.shape == (0, 3, 1)
+        rng = synth.rng_for(32)
+        x, m = synth.token_block(rng, 2, 3, 7, 20)
+        y, hm = enc((x, m))
+        yo, hmo = O.text_encoder(x, m, sd, 5)
+        H.assert_close(y, yo)
+        assert torch.equal(hm.cpu(), hmo)
+
+
+def test_cpu_tensors_fail_loudly():
+    from xnrs_amd.hip import XnrsHipError
+    pool = layers.AdditiveAttention(8, 4)  # left on the CPU
+    with torch.no_grad(), pytest.raises(XnrsHipError):
+        pool(torch.zeros(1, 2, 8), None)

@@ -1,0 +1,302 @@
+// extern "C" entry points of libxnrs_hip.so (declared in include/xnrs_hip.h) and the host-side
+// orchestration of the kernel pipeline.  No allocation, no sync, no global state: everything is
+// enqueued on the caller's stream into the caller's workspace (hipGraph-capturable).
+//
+// Sequence-encoder pipeline (TextEncoder news_encoding.py:34-60 / UserEncoder user_encoding.py:50-81),
+// per chunk of sequences:
+//   [att]   QKV = x.[Wq|Wk|Wv]^T + b   (one 3-segment MFMA GEMM, optional id-gather on the rows)
+//           O   = softmax(rowmask(QK^T/sqrt(dk))) V          (mha_core, per sequence/head/q-tile)
+//           Y   = O.Wo^T + bo                                  (MFMA GEMM)
+//   [pool]  T   = tanh(Y.W1^T + b1)                            (MFMA GEMM, tanh epilogue)
+//           p   = sum_i a_i Y_i,  a = exp(T.w2+b2)*m / (sum+1e-8)   (additive_pool)  | masked mean
+//   [head]  y   = W4 relu(W3 p + b3) + b4                      (two MFMA GEMMs over all sequences)
+#include "../../include/xnrs_hip.h"
+#include "kernels.h"
+
+using namespace xnrs;
+
+namespace {
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+struct Plan {
+  int64_t chunk;  // sequences per pass
+  size_t off_qkv, off_o, off_y, off_t, off_p, off_h;
+  size_t total;
+};
+
+// workspace carve for one chunk; every region 256-B aligned
+Plan make_plan(int64_t n_seq, int L, int D, int A, int E, bool att, bool additive, bool head, bool pooled, int64_t chunk) {
+  Plan p{};
+  if (chunk <= 0) chunk = (65536 + L - 1) / L;  // ~64k rows per pass
+  if (chunk > n_seq) chunk = n_seq;
+  if (chunk < 1) chunk = 1;
+  p.chunk = chunk;
+  const size_t rows = (size_t)chunk * L;
+  size_t off = 0;
+  auto take = [&](size_t nfloat) {
+    size_t o = off;
+    off += align_up(nfloat * sizeof(float));
+    return o;
+  };
+  p.off_qkv = att ? take(rows * 3 * (size_t)D) : 0;
+  p.off_o = att ? take(rows * (size_t)D) : 0;
+  p.off_y = (att && pooled) ? take(rows * (size_t)D) : 0;  // att output when a pooler follows
+  p.off_t = (pooled && additive) ? take(rows * (size_t)A) : 0;
+  p.off_p = (pooled && head) ? take((size_t)chunk * D) : 0;
+  p.off_h = (pooled && head) ? take((size_t)chunk * E) : 0;
+  p.total = off;
+  return p;
+}
+
+int32_t hip_rc(hipError_t e) { return e == hipSuccess ? XNRS_OK : (int32_t)e; }
+
+#define XNRS_TRY(expr)                    \
+  do {                                    \
+    hipError_t _e = (expr);               \
+    if (_e != hipSuccess) return hip_rc(_e); \
+  } while (0)
+
+GemmArgs gemm1(const float* A, const int32_t* ids, int gS, int64_t lda, const float* W, const float* b, float* C,
+               int64_t ldc, int64_t M, int N, int K, int act) {
+  GemmArgs g{};
+  g.A = A;
+  g.gather_ids = ids;
+  g.gather_S = gS;
+  g.lda = lda;
+  g.W[0] = W;
+  g.bias[0] = b;
+  g.nseg = 1;
+  g.Nseg = N;
+  g.ldw = K;
+  g.C = C;
+  g.ldc = ldc;
+  g.M = M;
+  g.K = K;
+  g.act = act;
+  return g;
+}
+
+// x:(n_seq,L,D) [or table + ids], m:(n_seq,L) [or table mask] -> y
+//   pooled == false: y:(n_seq,L,D) = att(x)            (MultiHeadAttention alone)
+//   pooled == true : y:(n_seq,E')  = head(pool(att(x)))
+int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n_seq, int L, int D,
+                   const xnrs_mha_params* att, bool pooled, int pool_kind, const xnrs_additive_params* pool,
+                   const xnrs_head_params* head, float* y, float* a_out, float* hm, int64_t chunk, void* ws,
+                   size_t ws_bytes, hipStream_t stream) {
+  if (n_seq < 0 || L <= 0 || D <= 0 || !x || !y) return XNRS_EINVAL;
+  if (n_seq == 0) return XNRS_OK;
+  if (att) {
+    if (att->n_heads <= 0 || !att->wq || !att->wk || !att->wv || !att->wo) return XNRS_EINVAL;
+    if (D % att->n_heads != 0) return XNRS_EHEADS;
+    if (L > 128) return XNRS_EUNSUPPORTED;
+  }
+  const bool additive = pooled && pool_kind == XNRS_POOL_ADDITIVE;
+  if (pooled) {
+    if (pool_kind != XNRS_POOL_ADDITIVE && pool_kind != XNRS_POOL_MEAN) return XNRS_EINVAL;
+    if (additive && (!pool || !pool->w1 || !pool->w2 || pool->hidden <= 0)) return XNRS_EINVAL;
+    if (pool_kind == XNRS_POOL_MEAN && !m) return XNRS_EINVAL;
+    if (L > 512) return XNRS_EUNSUPPORTED;
+    if (head && (!head->w0 || !head->w2 || head->out_features <= 0)) return XNRS_EINVAL;
+  }
+  if (ids && !m && pooled && pool_kind == XNRS_POOL_MEAN) return XNRS_EINVAL;
+  const int A = additive ? pool->hidden : 0;
+  const int E = (pooled && head) ? head->out_features : D;
+  const Plan p = make_plan(n_seq, L, D, A, E, att != nullptr, additive, pooled && head, pooled, chunk);
+  if (p.total > ws_bytes || (p.total > 0 && !ws)) return XNRS_EWORKSPACE;
+  char* w = static_cast<char*>(ws);
+  float* qkv = reinterpret_cast<float*>(w + p.off_qkv);
+  float* o = reinterpret_cast<float*>(w + p.off_o);
+  float* yb = reinterpret_cast<float*>(w + p.off_y);
+  float* t = reinterpret_cast<float*>(w + p.off_t);
+  float* pb = reinterpret_cast<float*>(w + p.off_p);
+  float* hb = reinterpret_cast<float*>(w + p.off_h);
+
+  for (int64_t c0 = 0; c0 < n_seq; c0 += p.chunk) {
+    const int64_t nc = (n_seq - c0 < p.chunk) ? (n_seq - c0) : p.chunk;
+    const int64_t rows = nc * L;
+    // this chunk's view of the inputs
+    const int32_t* cids = ids ? ids + c0 : nullptr;
+    const float* cx = ids ? x : x + c0 * (int64_t)L * D;      // table stays whole when gathering
+    const float* cm = m ? (ids ? m : m + c0 * (int64_t)L) : nullptr;
+
+    const float* seq = cx;            // what the pooler sees
+    const int32_t* seq_ids = cids;    // gather for the pooler's value rows
+    if (att) {
+      GemmArgs g{};
+      g.A = cx;
+      g.gather_ids = cids;
+      g.gather_S = L;
+      g.lda = D;
+      g.W[0] = att->wq; g.W[1] = att->wk; g.W[2] = att->wv;
+      g.bias[0] = att->bq; g.bias[1] = att->bk; g.bias[2] = att->bv;
+      g.nseg = 3;
+      g.Nseg = D;
+      g.ldw = D;
+      g.C = qkv;
+      g.ldc = 3 * (int64_t)D;
+      g.M = rows;
+      g.K = D;
+      g.act = XNRS_ACT_NONE;
+      XNRS_TRY(launch_gemm_f32(g, stream));
+
+      MhaCoreArgs ma{};
+      ma.q = qkv;
+      ma.k = qkv + D;
+      ma.v = qkv + 2 * (int64_t)D;
+      ma.ld = 3 * (int64_t)D;
+      ma.mask = cm;
+      ma.mask_gather_ids = cids;
+      ma.out = o;
+      ma.ldo = D;
+      ma.n_seq = nc;
+      ma.S = L;
+      ma.n_heads = att->n_heads;
+      ma.d_k = D / att->n_heads;
+      ma.scaled = att->scaled;
+      ma.dropout_p = att->dropout_p;
+      ma.seed = att->seed + (uint64_t)c0 * 0x9E3779B97F4A7C15ull;
+      XNRS_TRY(launch_mha_core(ma, stream));
+
+      float* dst = pooled ? yb : y + c0 * (int64_t)L * D;
+      XNRS_TRY(launch_gemm_f32(gemm1(o, nullptr, 0, D, att->wo, att->bo, dst, D, rows, D, D, XNRS_ACT_NONE), stream));
+      seq = dst;
+      seq_ids = nullptr;
+    }
+    if (!pooled) continue;
+
+    float* pooled_dst = head ? pb : y + c0 * (int64_t)D;
+    float* hm_dst = hm ? hm + c0 : nullptr;
+    if (additive) {
+      XNRS_TRY(launch_gemm_f32(gemm1(seq, seq_ids, L, D, pool->w1, pool->b1, t, A, rows, A, D, XNRS_ACT_TANH), stream));
+      AdditivePoolArgs pa{};
+      pa.t = t;
+      pa.w2 = pool->w2;
+      pa.b2 = pool->b2;
+      pa.mask = cm;
+      pa.mask_gather_ids = cids;
+      pa.x_gather_ids = seq_ids;
+      pa.x = seq;
+      pa.ldx = D;
+      pa.y = pooled_dst;
+      pa.a_out = a_out ? a_out + c0 * (int64_t)L : nullptr;
+      pa.hm_out = cm ? hm_dst : nullptr;
+      pa.n_seq = nc;
+      pa.N = L;
+      pa.D = D;
+      pa.A = A;
+      XNRS_TRY(launch_additive_pool(pa, stream));
+    } else {
+      MeanPoolArgs mp{};
+      mp.x = seq;
+      mp.ldx = D;
+      mp.mask = cm;
+      mp.mask_gather_ids = cids;
+      mp.x_gather_ids = seq_ids;
+      mp.y = pooled_dst;
+      mp.hm_out = hm_dst;
+      mp.n_seq = nc;
+      mp.N = L;
+      mp.D = D;
+      XNRS_TRY(launch_mean_pool(mp, stream));
+    }
+    if (head) {
+      XNRS_TRY(launch_gemm_f32(gemm1(pb, nullptr, 0, D, head->w0, head->b0, hb, E, nc, E, D, XNRS_ACT_RELU), stream));
+      XNRS_TRY(launch_gemm_f32(gemm1(hb, nullptr, 0, E, head->w2, head->b2, y + c0 * (int64_t)E, E, nc, E, E,
+                                     XNRS_ACT_NONE),
+                               stream));
+    }
+  }
+  return XNRS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t xnrs_abi_version(void) { return XNRS_ABI_VERSION; }
+
+const char* xnrs_error_string(int32_t code) {
+  switch (code) {
+    case XNRS_OK: return "ok";
+    case XNRS_EINVAL: return "invalid argument (shape or NULL pointer)";
+    case XNRS_EHEADS: return "d_model is not divisible by n_heads";
+    case XNRS_EWORKSPACE: return "workspace too small";
+    case XNRS_EUNSUPPORTED: return "shape outside the supported range (attention S <= 128, pooling N <= 512)";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+  }
+}
+
+int32_t xnrs_linear_fwd(const float* x, const int32_t* gather_ids, int32_t gather_S, const float* w, const float* bias,
+                        float* y, int64_t M, int32_t N, int32_t K, int32_t act, void* stream) {
+  if (!x || !w || !y || M < 0 || N <= 0 || K <= 0 || act < 0 || act > 2) return XNRS_EINVAL;
+  if (gather_ids && gather_S <= 0) return XNRS_EINVAL;
+  return hip_rc(launch_gemm_f32(gemm1(x, gather_ids, gather_S, K, w, bias, y, N, M, N, K, act), (hipStream_t)stream));
+}
+
+size_t xnrs_mha_workspace_bytes(int64_t B, int32_t S, int32_t D) {
+  return make_plan(B, S, D, 0, D, true, false, false, false, 0).total;
+}
+
+int32_t xnrs_mha_fwd(const float* x, const float* m, const xnrs_mha_params* p, float* y, int64_t B, int32_t S, int32_t D,
+                     void* ws, size_t ws_bytes, void* stream) {
+  if (!p) return XNRS_EINVAL;
+  return seq_encode(x, m, nullptr, B, S, D, p, false, 0, nullptr, nullptr, y, nullptr, nullptr, 0, ws, ws_bytes,
+                    (hipStream_t)stream);
+}
+
+size_t xnrs_additive_workspace_bytes(int64_t B, int32_t N, int32_t D, int32_t A) {
+  return make_plan(B, N, D, A, D, false, true, false, true, 0).total;
+}
+
+int32_t xnrs_additive_attention_fwd(const float* x, const float* m, const xnrs_additive_params* p, float* y, float* a_out,
+                                    int64_t B, int32_t N, int32_t D, void* ws, size_t ws_bytes, void* stream) {
+  if (!p) return XNRS_EINVAL;
+  return seq_encode(x, m, nullptr, B, N, D, nullptr, true, XNRS_POOL_ADDITIVE, p, nullptr, y, a_out, nullptr, 0, ws,
+                    ws_bytes, (hipStream_t)stream);
+}
+
+int32_t xnrs_masked_mean_fwd(const float* x, const float* m, float* y, int64_t B, int32_t N, int32_t D, void* stream) {
+  return seq_encode(x, m, nullptr, B, N, D, nullptr, true, XNRS_POOL_MEAN, nullptr, nullptr, y, nullptr, nullptr, 0,
+                    nullptr, 0, (hipStream_t)stream);
+}
+
+int32_t xnrs_collapse_mask(const float* m, float* hm, int64_t n_rows, int32_t S, void* stream) {
+  if (!m || !hm || n_rows < 0 || S <= 0) return XNRS_EINVAL;
+  return hip_rc(launch_collapse_mask(m, nullptr, hm, n_rows, S, (hipStream_t)stream));
+}
+
+size_t xnrs_text_encoder_workspace_bytes(int64_t n_news, int32_t S, int32_t D, int32_t A, int32_t E, int32_t has_att,
+                                         int32_t pool_kind, int32_t has_head, int64_t chunk) {
+  return make_plan(n_news, S, D, A, E, has_att != 0, pool_kind == XNRS_POOL_ADDITIVE, has_head != 0, true, chunk).total;
+}
+
+int32_t xnrs_text_encoder_fwd(const float* x, const float* m, const int32_t* ids, int64_t n_news, int32_t S, int32_t D,
+                              const xnrs_mha_params* att, int32_t pool_kind, const xnrs_additive_params* pool,
+                              const xnrs_head_params* head, float* y, float* hm, int64_t chunk, void* ws, size_t ws_bytes,
+                              void* stream) {
+  if (!m) return XNRS_EINVAL;  // TextEncoder always receives a token mask (news_encoding.py:41-50)
+  int32_t rc = seq_encode(x, m, ids, n_news, S, D, att, true, pool_kind, pool, head, y, nullptr, hm, chunk, ws, ws_bytes,
+                          (hipStream_t)stream);
+  return rc;
+}
+
+size_t xnrs_user_encoder_workspace_bytes(int64_t B, int32_t H, int32_t E, int32_t A, int32_t has_att, int32_t pool_kind,
+                                         int32_t has_head) {
+  return make_plan(B, H, E, A, E, has_att != 0, pool_kind == XNRS_POOL_ADDITIVE, has_head != 0, true, 0).total;
+}
+
+int32_t xnrs_user_encoder_fwd(const float* x, const float* m, int64_t B, int32_t H, int32_t E, const xnrs_mha_params* att,
+                              int32_t pool_kind, const xnrs_additive_params* pool, const xnrs_head_params* head, float* y,
+                              float* a_out, void* ws, size_t ws_bytes, void* stream) {
+  return seq_encode(x, m, nullptr, B, H, E, att, true, pool_kind, pool, head, y, a_out, nullptr, 0, ws, ws_bytes,
+                    (hipStream_t)stream);
+}
+
+int32_t xnrs_dot_scoring_fwd(const float* u, const float* c, float* r, int64_t B, int32_t C, int32_t E, int32_t normalize,
+                             void* stream) {
+  if (!u || !c || !r || B < 0 || C <= 0 || E <= 0) return XNRS_EINVAL;
+  return hip_rc(launch_dot_scoring(u, c, r, B, C, E, normalize, (hipStream_t)stream));
+}
+
+}  // extern "C"

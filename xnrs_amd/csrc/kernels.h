@@ -1,0 +1,88 @@
+// Internal launcher declarations shared by the .hip translation units of libxnrs_hip.so.
+// gfx950 (MI355X / CDNA4) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace xnrs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------- Linear (fp32 MFMA GEMM)
+// C[M, nseg*Nseg] = act(A[M,K] . W_s[Nseg,K]^T + bias_s), s = column segment (up to 3 weights
+// side by side: the Q/K/V projections share one launch while the parameters stay separate
+// tensors, as the reference's state_dict requires).
+struct GemmArgs {
+  const float* A;
+  const int32_t* gather_ids;  // nullable: logical row m -> table row ids[m/gather_S]*gather_S + m%gather_S
+  int32_t gather_S;
+  int64_t lda;  // row stride of A in floats
+  const float* W[3];
+  const float* bias[3];  // nullable each
+  int32_t nseg;
+  int32_t Nseg;  // columns per segment
+  int64_t ldw;   // row stride of every W in floats
+  float* C;
+  int64_t ldc;
+  int64_t M;
+  int32_t K;
+  int32_t act;
+};
+hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t stream);
+
+// ---------------------------------------------------------------- attention core (QK^T, row mask, softmax, PV)
+struct MhaCoreArgs {
+  const float* q;  // element (row, col) at q[row*ld + head*d_k + col]
+  const float* k;
+  const float* v;
+  int64_t ld;         // row stride (floats) of q/k/v
+  const float* mask;  // [n_seq*S] fp32 0/1 or null (QUERY-row mask, layers.py:142-144)
+  const int32_t* mask_gather_ids;  // nullable: mask row of sequence n is ids[n]
+  float* out;         // [n_seq*S, ldo]; head h writes columns [h*d_k, (h+1)*d_k)
+  int64_t ldo;
+  int64_t n_seq;
+  int32_t S, n_heads, d_k;
+  int32_t scaled;
+  float dropout_p;
+  uint64_t seed;
+};
+hipError_t launch_mha_core(const MhaCoreArgs& a, hipStream_t stream);
+
+// ---------------------------------------------------------------- pooling / scoring
+struct AdditivePoolArgs {
+  const float* t;    // [n_seq*N, A] = tanh(fc1(x)) (the tanh is fused into the fc1 GEMM epilogue)
+  const float* w2;   // [A]
+  const float* b2;   // [1]
+  const float* mask; // [n_seq*N] or null
+  const int32_t* mask_gather_ids;  // nullable: mask rows of sequence n come from table row ids[n]
+  const int32_t* x_gather_ids;     // nullable: value rows of sequence n come from table row ids[n]
+  const float* x;    // [n_seq*N, ldx] values to pool (or table)
+  int64_t ldx;
+  float* y;          // [n_seq, D]
+  float* a_out;      // [n_seq*N] or null
+  float* hm_out;     // [n_seq] or null : clamp(sum mask,0,1)
+  int64_t n_seq;
+  int32_t N, D, A;
+};
+hipError_t launch_additive_pool(const AdditivePoolArgs& a, hipStream_t stream);
+
+struct MeanPoolArgs {
+  const float* x;
+  int64_t ldx;
+  const float* mask;  // [n_seq*N] (required)
+  const int32_t* mask_gather_ids;
+  const int32_t* x_gather_ids;
+  float* y;           // [n_seq, D]
+  float* hm_out;      // nullable
+  int64_t n_seq;
+  int32_t N, D;
+};
+hipError_t launch_mean_pool(const MeanPoolArgs& a, hipStream_t stream);
+
+hipError_t launch_collapse_mask(const float* m, const int32_t* gather_ids, float* hm, int64_t n_rows, int32_t S,
+                                hipStream_t stream);
+hipError_t launch_dot_scoring(const float* u, const float* c, float* r, int64_t B, int32_t C, int32_t E,
+                              int32_t normalize, hipStream_t stream);
+
+}  // namespace xnrs

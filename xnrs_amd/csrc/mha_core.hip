@@ -1,0 +1,204 @@
+// Attention core of layers.MultiHeadAttention.forward (xnrs/models/components/layers.py:133-153):
+// per (sequence, head):  P = softmax(rowmask(Q K^T / sqrt(d_k)));  O = P V   -- fp32, MFMA 16x16x4.
+//
+// Parity-critical semantics reproduced exactly (SURVEY.md finding 4):
+//   * the mask is a QUERY-ROW mask (layers.py:142-144): a row with m==0 is filled with -1e9 for ALL
+//     keys, so its softmax is exactly uniform 1/S; valid rows attend over all S keys incl. padded.
+//   * softmax is max-stabilised like torch.softmax; the scale is a true division by sqrt(d_k).
+//
+// Work decomposition: one wave per (sequence, head, 16-query tile); 4 waves per workgroup.  S <= 128
+// (8 key tiles).  No LDS: all operands go global -> VGPR in MFMA layout.
+//   * S^T tile = K_h . Q_h^T is computed (keys on the MFMA rows, queries on the lanes' column),
+//     so after the MFMA lane (c = lane&15, g = lane>>4) holds S[query c][key 16*kt + 4g + r],
+//     r = 0..3: the softmax reduction over keys is in-lane + two wavefront shuffles (xor 16, 32),
+//     and the probabilities are ALREADY in the B-operand layout of the second product
+//     O^T = V_h^T . P^T  (k index = key), so P never leaves registers.
+//   * Q/K fragments are 16-byte loads (4 consecutive features per lane; MFMA step r uses feature
+//     16*fb + 4g + r for both operands), V fragments are dword loads with the 16 lanes of a group on
+//     16 consecutive floats.
+//   * the output comes out as O^T[dv = 16*dt + 4g + r][query c]: 4 consecutive dv per lane -> one
+//     16-byte store per lane straight into the (M, D) "concat heads" layout (layers.py:153).
+#include "kernels.h"
+
+namespace xnrs {
+
+// counter-based RNG for attention dropout (training mode only): splitmix64 finaliser on
+// (seed, element index) -> uniform [0,1).  Parity with torch's CPU Philox stream is impossible
+// (SURVEY.md section 7 "hard parts"); only the distribution matters.
+__device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+template <int KT, bool VEC>
+__global__ __launch_bounds__(256) void mha_core_kernel(MhaCoreArgs a, int QT, int64_t n_units) {
+  const int lane = threadIdx.x & 63;
+  const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit >= n_units) return;  // wave-uniform
+  const int qt = (int)(unit % QT);
+  const int64_t uh = unit / QT;
+  const int hd = (int)(uh % a.n_heads);
+  const int64_t seq = uh / a.n_heads;
+
+  const int c = lane & 15, g = lane >> 4;
+  const int S = a.S, dk = a.d_k;
+  const int64_t row0 = seq * S;
+  const int hoff = hd * dk;
+  const int query = qt * 16 + c;
+  const bool qvalid = query < S;
+
+  // ---------------- S^T = K Q^T
+  f32x4 acc[KT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const float* qrow = a.q + (row0 + (qvalid ? query : 0)) * a.ld + hoff;
+  const int nfb = (dk + 15) >> 4;
+  for (int fb = 0; fb < nfb; ++fb) {
+    const int f0 = fb * 16 + 4 * g;
+    f32x4 qf = {0.f, 0.f, 0.f, 0.f};
+    if (qvalid) {
+      if (VEC) {
+        if (f0 < dk) qf = *reinterpret_cast<const f32x4*>(qrow + f0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (f0 + e < dk) qf[e] = qrow[f0 + e];
+      }
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      const int key = kt * 16 + c;
+      f32x4 kf = {0.f, 0.f, 0.f, 0.f};
+      if (key < S) {
+        const float* krow = a.k + (row0 + key) * a.ld + hoff;
+        if (VEC) {
+          if (f0 < dk) kf = *reinterpret_cast<const f32x4*>(krow + f0);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (f0 + e < dk) kf[e] = krow[f0 + e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qf[e], acc[kt], 0, 0, 0);
+    }
+  }
+
+  // ---------------- scale, row mask, softmax over keys (acc[kt][r] = S[query][16kt+4g+r])
+  float mq = 1.f;
+  if (a.mask && qvalid) {
+    const int64_t mrow = a.mask_gather_ids ? (int64_t)a.mask_gather_ids[seq] * S : row0;
+    mq = a.mask[mrow + query];
+  }
+  const float sq = sqrtf((float)dk);
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kt * 16 + 4 * g + r;
+      float s = acc[kt][r];
+      if (a.scaled) s = s / sq;
+      if (mq == 0.f) s = -1e9f;
+      if (key >= S) s = -INFINITY;
+      acc[kt][r] = s;
+      mx = fmaxf(mx, s);
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float e = expf(acc[kt][r] - mx);  // exp(-inf) = 0 for padding keys
+      acc[kt][r] = e;
+      sum += e;
+    }
+  }
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  const float keep = 1.f - a.dropout_p;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float p = acc[kt][r] / sum;
+      if (a.dropout_p > 0.f) {  // nn.Dropout on the probabilities (layers.py:148), train mode only
+        const int key = kt * 16 + 4 * g + r;
+        const uint64_t idx = ((uint64_t)(seq * a.n_heads + hd) * S + (uint64_t)query) * S + (uint64_t)key;
+        p = (uniform01(a.seed, idx) < keep) ? p / keep : 0.f;
+      }
+      acc[kt][r] = p;
+    }
+  }
+
+  // ---------------- O^T = V^T P^T
+  const int ndt = (dk + 15) >> 4;
+  for (int dt = 0; dt < ndt; ++dt) {
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    const int dv_a = dt * 16 + c;  // the V column this lane feeds as MFMA row
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      float vv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + 4 * g + r;
+        vv[r] = (key < S && dv_a < dk) ? a.v[(row0 + key) * a.ld + hoff + dv_a] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[r], acc[kt][r], o, 0, 0, 0);
+    }
+    // o[r] = O[query c][dv = 16dt + 4g + r]
+    if (qvalid) {
+      const int dv0 = dt * 16 + 4 * g;
+      float* orow = a.out + (row0 + query) * a.ldo + hoff + dv0;
+      if (VEC) {
+        if (dv0 < dk) *reinterpret_cast<f32x4*>(orow) = o;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (dv0 + r < dk) orow[r] = o[r];
+      }
+    }
+  }
+}
+
+template <int KT>
+static hipError_t launch_kt(const MhaCoreArgs& a, bool vec, hipStream_t stream) {
+  const int QT = (a.S + 15) / 16;
+  const int64_t n_units = a.n_seq * a.n_heads * QT;
+  const int64_t grid = (n_units + 3) / 4;
+  if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  if (vec)
+    hipLaunchKernelGGL((mha_core_kernel<KT, true>), dim3((unsigned)grid), dim3(256), 0, stream, a, QT, n_units);
+  else
+    hipLaunchKernelGGL((mha_core_kernel<KT, false>), dim3((unsigned)grid), dim3(256), 0, stream, a, QT, n_units);
+  return hipGetLastError();
+}
+
+hipError_t launch_mha_core(const MhaCoreArgs& a, hipStream_t stream) {
+  if (a.n_seq <= 0 || a.S <= 0) return hipSuccess;
+  if (a.S > 128) return hipErrorInvalidValue;
+  const bool vec = (a.d_k % 4 == 0) && (a.ld % 4 == 0) && (a.ldo % 4 == 0) &&
+                   ((reinterpret_cast<uintptr_t>(a.q) & 15) == 0) && ((reinterpret_cast<uintptr_t>(a.k) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0);
+  const int KT = (a.S + 15) / 16;
+  switch (KT) {
+    case 1: return launch_kt<1>(a, vec, stream);
+    case 2: return launch_kt<2>(a, vec, stream);
+    case 3: return launch_kt<3>(a, vec, stream);
+    case 4: return launch_kt<4>(a, vec, stream);
+    case 5: return launch_kt<5>(a, vec, stream);
+    case 6: return launch_kt<6>(a, vec, stream);
+    case 7: return launch_kt<7>(a, vec, stream);
+    default: return launch_kt<8>(a, vec, stream);
+  }
+}
+
+}  // namespace xnrs

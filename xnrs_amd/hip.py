@@ -1,0 +1,173 @@
+"""ctypes binding of libxnrs_hip.so (the C ABI declared in include/xnrs_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing, or a tensor is not on a HIP
+device, these functions raise.  PyTorch is used only for device memory, streams and autograd
+plumbing -- no torch op computes any part of the hot path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libxnrs_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+POOL_ADDITIVE, POOL_MEAN = 0, 1
+
+#: every symbol include/xnrs_hip.h declares (checked by tests/test_abi.py against the header text)
+SYMBOLS = (
+    "xnrs_abi_version", "xnrs_error_string", "xnrs_linear_fwd", "xnrs_mha_workspace_bytes", "xnrs_mha_fwd",
+    "xnrs_additive_workspace_bytes", "xnrs_additive_attention_fwd", "xnrs_masked_mean_fwd", "xnrs_collapse_mask",
+    "xnrs_text_encoder_workspace_bytes", "xnrs_text_encoder_fwd", "xnrs_user_encoder_workspace_bytes",
+    "xnrs_user_encoder_fwd", "xnrs_dot_scoring_fwd",
+)
+
+
+class XnrsHipError(RuntimeError):
+    pass
+
+
+class MhaParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo")] + [
+        ("n_heads", C.c_int32), ("scaled", C.c_int32), ("dropout_p", C.c_float), ("seed", C.c_uint64)]
+
+
+class AdditiveParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w1", "b1", "w2", "b2")] + [("hidden", C.c_int32)]
+
+
+class HeadParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w0", "b0", "w2", "b2")] + [("out_features", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libxnrs_hip.so once.  Missing library = hard error (no CPU / eager fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise XnrsHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C xnrs_amd/csrc`).  xnrs_amd has no non-HIP fallback.")
+    l = C.CDLL(LIB_PATH)
+    p, i32, i64, sz, f = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t, C.c_float
+    l.xnrs_abi_version.restype = i32
+    l.xnrs_abi_version.argtypes = []
+    l.xnrs_error_string.restype = C.c_char_p
+    l.xnrs_error_string.argtypes = [i32]
+    l.xnrs_linear_fwd.restype = i32
+    l.xnrs_linear_fwd.argtypes = [p, p, i32, p, p, p, i64, i32, i32, i32, p]
+    l.xnrs_mha_workspace_bytes.restype = sz
+    l.xnrs_mha_workspace_bytes.argtypes = [i64, i32, i32]
+    l.xnrs_mha_fwd.restype = i32
+    l.xnrs_mha_fwd.argtypes = [p, p, C.POINTER(MhaParams), p, i64, i32, i32, p, sz, p]
+    l.xnrs_additive_workspace_bytes.restype = sz
+    l.xnrs_additive_workspace_bytes.argtypes = [i64, i32, i32, i32]
+    l.xnrs_additive_attention_fwd.restype = i32
+    l.xnrs_additive_attention_fwd.argtypes = [p, p, C.POINTER(AdditiveParams), p, p, i64, i32, i32, p, sz, p]
+    l.xnrs_masked_mean_fwd.restype = i32
+    l.xnrs_masked_mean_fwd.argtypes = [p, p, p, i64, i32, i32, p]
+    l.xnrs_collapse_mask.restype = i32
+    l.xnrs_collapse_mask.argtypes = [p, p, i64, i32, p]
+    l.xnrs_text_encoder_workspace_bytes.restype = sz
+    l.xnrs_text_encoder_workspace_bytes.argtypes = [i64, i32, i32, i32, i32, i32, i32, i32, i64]
+    l.xnrs_text_encoder_fwd.restype = i32
+    l.xnrs_text_encoder_fwd.argtypes = [p, p, p, i64, i32, i32, C.POINTER(MhaParams), i32, C.POINTER(AdditiveParams),
+                                        C.POINTER(HeadParams), p, p, i64, p, sz, p]
+    l.xnrs_user_encoder_workspace_bytes.restype = sz
+    l.xnrs_user_encoder_workspace_bytes.argtypes = [i64, i32, i32, i32, i32, i32, i32]
+    l.xnrs_user_encoder_fwd.restype = i32
+    l.xnrs_user_encoder_fwd.argtypes = [p, p, i64, i32, i32, C.POINTER(MhaParams), i32, C.POINTER(AdditiveParams),
+                                        C.POINTER(HeadParams), p, p, p, sz, p]
+    l.xnrs_dot_scoring_fwd.restype = i32
+    l.xnrs_dot_scoring_fwd.argtypes = [p, p, p, i64, i32, i32, i32, p]
+    if l.xnrs_abi_version() != 1:
+        raise XnrsHipError("libxnrs_hip.so ABI version mismatch; rebuild it")
+    _lib = l
+    return l
+
+
+def check(rc: int, what: str):
+    if rc == 0:
+        return
+    msg = lib().xnrs_error_string(rc).decode()
+    if rc == -2:
+        # same exception type as the reference's failing .view() (layers.py:111,133)
+        raise RuntimeError(f"{what}: {msg}")
+    raise XnrsHipError(f"{what}: {msg} (code {rc})")
+
+
+# ---------------------------------------------------------------------------------- tensor plumbing
+def dev_f32(t: torch.Tensor, what: str) -> torch.Tensor:
+    """Contiguous fp32 HIP tensor or a loud error (never a silent CPU path)."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{what}: expected a tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise XnrsHipError(f"{what}: tensor is on {t.device}; xnrs_amd runs on a HIP device only "
+                           "(move the module and inputs to 'cuda'; there is no CPU fallback)")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+_workspaces = {}
+
+
+def workspace(device, nbytes: int) -> Optional[torch.Tensor]:
+    """Grow-only per-(device, stream) scratch buffer handed to the library (it never allocates)."""
+    if nbytes == 0:
+        return None
+    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = None
+        _workspaces.pop(key, None)
+        buf = torch.empty(int(nbytes * 1.05) + 256, dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def release_workspaces():
+    _workspaces.clear()
+
+
+# ---------------------------------------------------------------------------------- parameter packs
+def mha_params(att, dropout_p: float = 0.0, seed: int = 0):
+    """(MhaParams, keepalive list) from an xnrs_amd MultiHeadAttention module."""
+    ts = [dev_f32(t, "mha weight") for t in (
+        att.q_linear.weight, att.q_linear.bias, att.k_linear.weight, att.k_linear.bias,
+        att.v_linear.weight, att.v_linear.bias, att.out.weight, att.out.bias)]
+    p = MhaParams(*[t.data_ptr() for t in ts], att.h, 1 if att.scaled else 0, float(dropout_p), int(seed))
+    return p, ts
+
+
+def additive_params(pool):
+    ts = [dev_f32(t, "additive weight") for t in (pool.fc1.weight, pool.fc1.bias, pool.fc2.weight, pool.fc2.bias)]
+    return AdditiveParams(*[t.data_ptr() for t in ts], pool.fc1.out_features), ts
+
+
+def head_params(head):
+    """nn.Sequential(Linear, act, Linear) -> HeadParams (the activation must be ReLU)."""
+    l0, l2 = head[0], head[2]
+    ts = [dev_f32(l0.weight, "head.0.weight"), None if l0.bias is None else dev_f32(l0.bias, "head.0.bias"),
+          dev_f32(l2.weight, "head.2.weight"), None if l2.bias is None else dev_f32(l2.bias, "head.2.bias")]
+    p = HeadParams(*[0 if t is None else t.data_ptr() for t in ts], l0.out_features)
+    for i in (1, 3):
+        if ts[i] is None:
+            setattr(p, ("w0", "b0", "w2", "b2")[i], None)
+    return p, ts
