@@ -1,0 +1,266 @@
+#!/usr/bin/env python
+"""bench.py -- impressions/s (encode + score) of the xnrs hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one pass of the hot path over one batch of synthetic MIND-shaped impressions whose
+token tensors are ALREADY RESIDENT in HBM: encode H history + C candidate news per impression with
+the NRMS news encoder, one user vector, C dot-product scores (ParentRec._forward,
+xnrs/models/components/parent.py:31-34), eval mode, no dedup.  Workload = BASELINE.json configs[2]
+at the reference's shipped token shape (config/mind_small_NRMS.yml): B=512, H=50, C=5, S=50, D=768,
+16 heads, E=256.  configs[1] (news encoder only, 1024 news) is reported under "extra".
+
+N>1: one process per GPU (launched by torch.distributed.run), impressions sharded by user, no
+data-path collective (weak scaling: every rank owns a full B=512 batch); the barrier/MAX reduction
+around the timed region is the only communication.
+
+The JSON line also carries
+  roofline     : the dominant kernel (the fused Q/K/V projection, an fp32-MFMA GEMM) -- algorithmic
+                 FLOPs per launch / its average launch duration, measured with HIP events inside
+                 the timed region (xnrs_profile_* in include/xnrs_hip.h), against the 157.3 TFLOP/s
+                 fp32 matrix peak (MI355X_MICROARCH.md).
+  cpu_baseline : the CPU oracle (oracle/xnrs_oracle.py, kind "port": the reference itself cannot
+                 travel to the GPU box) timed on the host cores on a bounded sample of the same
+                 workload, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from tests.golden import cases  # noqa: E402  (model_cfg: the flat YAML keys make_model reads)
+from xnrs_amd import hip, synth  # noqa: E402
+from xnrs_amd.models import make_model  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
+HBM_PEAK_GBS = 8000.0
+
+WORKLOAD = dict(B=512, H=50, C=5, S=50, D=768, h=16, E=256, A=256)
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def news_flops(S, D, A, E, att=True, head=True):
+    """algorithmic FLOPs per news item."""
+    f = 2 * S * D * A + 2 * S * A + 2 * S * D
+    if att:
+        f += 8 * S * D * D + 4 * S * S * D
+    if head:
+        f += 2 * D * E + 2 * E * E
+    return f
+
+
+def impression_flops(w):
+    n = (w["H"] + w["C"]) * news_flops(w["S"], w["D"], w["A"], w["E"])
+    u = 8 * w["H"] * w["E"] ** 2 + 4 * w["H"] ** 2 * w["E"] + 2 * w["H"] * w["E"] * w["A"] + 2 * w["H"] * w["A"] + 2 * w["H"] * w["E"]
+    return n + u + 2 * w["C"] * w["E"]
+
+
+def impression_bytes(w):
+    per_news = 4 * w["S"] * w["D"] + 4 * w["S"] + 4 * w["E"] + 4
+    return (w["H"] + w["C"]) * per_news + 4 * w["C"]
+
+
+def build_model(w, device, seed=1234):
+    c = dict(model="NRMS", E=w["E"], bias=False, h=w["h"], D=w["D"], H=w["H"], S=w["S"])
+    model = make_model(Cfg(cases.model_cfg(c)))
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth.fill_state_dict(shapes, seed)
+    model.load_state_dict(sd)
+    return model.eval().to(device), sd
+
+
+def make_inputs(w, device, seed):
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    B, H, C, S, D = w["B"], w["H"], w["C"], w["S"], w["D"]
+    hx, hm = synth.device_tokens(gen, B * H, S, D, device)
+    # ragged histories: trailing slots of each impression are empty (all-zero x and m, dataset.py:82-85)
+    n_hist = torch.randint(1, H + 1, (B, 1), generator=gen, device=device)
+    slot_valid = (torch.arange(H, device=device)[None, :] < n_hist).reshape(B * H, 1, 1).to(torch.float32)
+    hx.mul_(slot_valid)
+    hm.mul_(slot_valid)
+    cx, cm = synth.device_tokens(gen, B * C, S, D, device)
+    return (hx.reshape(B, H, S, D), hm.reshape(B, H, S, 1)), (cx.reshape(B, C, S, D), cm.reshape(B, C, S, 1))
+
+
+def step(model, hist, cand):
+    return model._forward(hist, cand)
+
+
+def timed(fn, steps, warmup, dist_on):
+    for _ in range(warmup):
+        fn()
+    if dist_on:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if dist_on:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def cpu_baseline(w, sd, sample_B=32, reps=3):
+    """Oracle (torch CPU fp32 restatement, pinned to the reference by tests/golden) on the host cores."""
+    from oracle import xnrs_oracle as O
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    rng_batch = synth.make_batch(77, sample_B, w["H"], w["C"], w["S"], w["D"], min_len=5)
+    hist = rng_batch["user_features"]["history"]["title_emb"]
+    cand = rng_batch["candidate_features"]["title_emb"]
+    sdc = {k: v.float().cpu() for k, v in sd.items()}
+    with torch.no_grad():
+        O.parent_forward(hist, cand, sdc, w["h"])  # warm-up
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = O.parent_forward(hist, cand, sdc, w["h"])
+        dt = (time.perf_counter() - t0) / reps
+    return dict(value=sample_B / dt, unit="impressions/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{sample_B} impressions of the same workload shape (H={w['H']},C={w['C']},S={w['S']},D={w['D']}), "
+                       f"{reps} timed passes after 1 warm-up, {dt:.2f} s/pass"), r
+
+
+def news_only_extra(device, steps=5, warmup=2):
+    """BASELINE configs[1]: NRMS news encoder only, 1024 news, at the reference-valid stand-ins of the
+    impossible 'd=300, 16 heads' (SURVEY.md finding 2) and at the shipped shape."""
+    out = {}
+    for name, (S, D, h) in {"S30_D300_h15": (30, 300, 15), "S30_D320_h16": (30, 320, 16), "S50_D768_h16": (50, 768, 16)}.items():
+        w = dict(B=1, H=1, C=1, S=S, D=D, h=h, E=256 if D != 300 else 240, A=256)
+        model, _ = build_model(w, device)
+        gen = torch.Generator(device=device)
+        gen.manual_seed(5)
+        x, m = synth.device_tokens(gen, 1024, S, D, device)
+        x, m = x.reshape(1, 1024, S, D), m.reshape(1, 1024, S, 1)
+        fn = lambda: model.news_encoder((x, m))  # noqa: E731
+        dt = timed(fn, steps, warmup, False) / steps
+        fl = 1024 * news_flops(S, D, 256, w["E"])
+        out[name] = dict(news_per_s=1024 / dt, ms=dt * 1e3, tflops=fl / dt / 1e12,
+                         frac_fp32_mfma=fl / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                         alg_gbs=1024 * (4 * S * D + 4 * S + 4 * w["E"] + 4) / dt / 1e9)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if dist_on:
+        torch.distributed.init_process_group("nccl", device_id=device)
+
+    w = WORKLOAD
+    model, sd = build_model(w, device)
+    hist, cand = make_inputs(w, device, seed=1000 + rank)  # each rank = its own shard of users
+
+    with torch.no_grad():
+        fn = lambda: step(model, hist, cand)  # noqa: E731
+        # warm-up outside the profiled region, then profile ONLY the dominant kernel (stage 0) live
+        for _ in range(args.warmup):
+            fn()
+        torch.cuda.synchronize()
+        hip.profile_enable(1)
+        dt = timed(fn, args.steps, 0, dist_on)
+        prof = hip.profile_read()
+        hip.profile_enable(0)
+        scores = fn()
+        torch.cuda.synchronize()
+
+    n_gpus = world
+    ms_per_step = dt / args.steps * 1e3
+    value = n_gpus * w["B"] * args.steps / dt
+
+    if rank == 0:
+        q_ms, q_n, q_fl = prof["qkv_gemm"]
+        ach = (q_fl / max(q_n, 1)) / (q_ms / max(q_n, 1) * 1e-3) / 1e12 if q_n else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("qkv_gemm_hbm_bytes_per_launch")
+        out = {
+            "metric": "impressions/sec (encode+score) on MIND-shaped batches",
+            "value": value,
+            "unit": "impressions/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "NRMS full user+news encode + 5-candidate dot scoring "
+                                   "(BASELINE configs[2]; token shape of config/mind_small_NRMS.yml)",
+                       "batch_impressions_per_gpu": w["B"], "history": w["H"], "candidates": w["C"],
+                       "tokens": w["S"], "d_backbone": w["D"], "n_heads": w["h"], "emb_dim": w["E"],
+                       "parallelism": f"impressions sharded by user over {n_gpus} GPU(s), no data-path collective"},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": "gemm_f32_kernel<2,2,true> (fused Q/K/V projection)",
+                         "launches_timed": q_n, "avg_launch_ms": q_ms / max(q_n, 1),
+                         "alg_flops_per_launch": q_fl / max(q_n, 1)},
+            "whole_path": {"alg_tflops": impression_flops(w) * value / n_gpus / 1e12,
+                           "frac_fp32_mfma": impression_flops(w) * value / n_gpus / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                           "alg_gbs": impression_bytes(w) * value / n_gpus / 1e9,
+                           "frac_hbm": impression_bytes(w) * value / n_gpus / 1e9 / HBM_PEAK_GBS},
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            cb, ref = cpu_baseline(w, sd)
+            out["cpu_baseline"] = cb
+            # parity spot-check of the benchmarked model on the CPU sample (same weights)
+            from oracle import xnrs_oracle as O  # noqa: F401
+            b = synth.make_batch(77, 32, w["H"], w["C"], w["S"], w["D"], min_len=5)
+            with torch.no_grad():
+                got = model._forward(b["user_features"]["history"]["title_emb"], b["candidate_features"]["title_emb"])
+            err = (got.cpu().double() - ref.double()).abs().max().item() / ref.abs().max().item()
+            out["parity_max_rel_err_vs_cpu"] = err
+        else:
+            out["cpu_baseline"] = None
+        if n_gpus == 1 and not args.no_extra:
+            with torch.no_grad():
+                out["extra"] = {"news_encoder_only_1024": news_only_extra(device)}
+                hip.profile_enable(0x3F)
+                fn()
+                torch.cuda.synchronize()
+                st = hip.profile_read()
+                hip.profile_enable(0)
+                out["extra"]["stage_ms_per_step"] = {k: round(v[0], 3) for k, v in st.items()}
+                out["extra"]["stage_tflops"] = {k: (v[2] / (v[0] * 1e-3) / 1e12 if v[0] > 0 else 0.0) for k, v in st.items()}
+        assert torch.isfinite(scores).all()
+        print(json.dumps(out))
+    if dist_on:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

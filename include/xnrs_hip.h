@@ -125,6 +125,18 @@ int32_t xnrs_user_encoder_fwd(const float *x, const float *m, int64_t B, int32_t
 int32_t xnrs_dot_scoring_fwd(const float *u, const float *c, float *r, int64_t B, int32_t C, int32_t E,
                              int32_t normalize, void *stream);
 
+/* ---- measurement aid (no reference counterpart) ----------------------------------------------
+ * When enabled, the sequence-encoder pipeline brackets each kernel launch of the selected stages
+ * with hipEvents on the caller's stream (the only process-global state in the library; off by
+ * default; not hipGraph-capturable while on).  stage_mask bit i selects stage i:
+ *   0 qkv GEMM | 1 attention core | 2 out-proj GEMM | 3 fc1+tanh GEMM | 4 pooling | 5 head GEMMs
+ * xnrs_profile_read synchronises the recorded events and returns, per stage, the summed launch
+ * duration (ms), the number of launches and the summed ALGORITHMIC flops of those launches
+ * (arrays of XNRS_PROFILE_STAGES entries), then clears the record. */
+#define XNRS_PROFILE_STAGES 6
+int32_t xnrs_profile_enable(uint32_t stage_mask);
+int32_t xnrs_profile_read(double *ms, int64_t *launches, double *flops);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,8 @@
 //   [pool]  T   = tanh(Y.W1^T + b1)                            (MFMA GEMM, tanh epilogue)
 //           p   = sum_i a_i Y_i,  a = exp(T.w2+b2)*m / (sum+1e-8)   (additive_pool)  | masked mean
 //   [head]  y   = W4 relu(W3 p + b3) + b4                      (two MFMA GEMMs over all sequences)
+#include <vector>
+
 #include "../../include/xnrs_hip.h"
 #include "kernels.h"
 
@@ -50,6 +52,38 @@ Plan make_plan(int64_t n_seq, int L, int D, int A, int E, bool att, bool additiv
 }
 
 int32_t hip_rc(hipError_t e) { return e == hipSuccess ? XNRS_OK : (int32_t)e; }
+
+// ---- optional per-launch event timing (measurement aid; see xnrs_profile_enable in the header)
+struct ProfRec {
+  hipEvent_t beg, end;
+  int stage;
+  double flops;
+};
+uint32_t g_prof_mask = 0;
+std::vector<ProfRec> g_prof;
+constexpr size_t PROF_MAX = 1 << 16;
+
+struct ProfScope {
+  bool on;
+  hipStream_t st;
+  ProfRec r{};
+  ProfScope(int stage, double flops, hipStream_t s) : on((g_prof_mask >> stage) & 1u), st(s) {
+    if (on && g_prof.size() >= PROF_MAX) on = false;
+    if (!on) return;
+    r.stage = stage;
+    r.flops = flops;
+    if (hipEventCreate(&r.beg) != hipSuccess || hipEventCreate(&r.end) != hipSuccess) {
+      on = false;
+      return;
+    }
+    (void)hipEventRecord(r.beg, st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(r.end, st);
+    g_prof.push_back(r);
+  }
+};
 
 #define XNRS_TRY(expr)                    \
   do {                                    \
@@ -138,7 +172,10 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
       g.M = rows;
       g.K = D;
       g.act = XNRS_ACT_NONE;
-      XNRS_TRY(launch_gemm_f32(g, stream));
+      {
+        ProfScope ps(0, 2.0 * rows * 3.0 * D * D, stream);
+        XNRS_TRY(launch_gemm_f32(g, stream));
+      }
 
       MhaCoreArgs ma{};
       ma.q = qkv;
@@ -156,10 +193,16 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
       ma.scaled = att->scaled;
       ma.dropout_p = att->dropout_p;
       ma.seed = att->seed + (uint64_t)c0 * 0x9E3779B97F4A7C15ull;
-      XNRS_TRY(launch_mha_core(ma, stream));
+      {
+        ProfScope ps(1, 4.0 * rows * (double)L * D, stream);
+        XNRS_TRY(launch_mha_core(ma, stream));
+      }
 
       float* dst = pooled ? yb : y + c0 * (int64_t)L * D;
-      XNRS_TRY(launch_gemm_f32(gemm1(o, nullptr, 0, D, att->wo, att->bo, dst, D, rows, D, D, XNRS_ACT_NONE), stream));
+      {
+        ProfScope ps(2, 2.0 * rows * (double)D * D, stream);
+        XNRS_TRY(launch_gemm_f32(gemm1(o, nullptr, 0, D, att->wo, att->bo, dst, D, rows, D, D, XNRS_ACT_NONE), stream));
+      }
       seq = dst;
       seq_ids = nullptr;
     }
@@ -168,7 +211,10 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
     float* pooled_dst = head ? pb : y + c0 * (int64_t)D;
     float* hm_dst = hm ? hm + c0 : nullptr;
     if (additive) {
-      XNRS_TRY(launch_gemm_f32(gemm1(seq, seq_ids, L, D, pool->w1, pool->b1, t, A, rows, A, D, XNRS_ACT_TANH), stream));
+      {
+        ProfScope ps(3, 2.0 * rows * (double)D * A, stream);
+        XNRS_TRY(launch_gemm_f32(gemm1(seq, seq_ids, L, D, pool->w1, pool->b1, t, A, rows, A, D, XNRS_ACT_TANH), stream));
+      }
       AdditivePoolArgs pa{};
       pa.t = t;
       pa.w2 = pool->w2;
@@ -185,7 +231,10 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
       pa.N = L;
       pa.D = D;
       pa.A = A;
-      XNRS_TRY(launch_additive_pool(pa, stream));
+      {
+        ProfScope ps(4, 2.0 * rows * (double)(A + D), stream);
+        XNRS_TRY(launch_additive_pool(pa, stream));
+      }
     } else {
       MeanPoolArgs mp{};
       mp.x = seq;
@@ -198,9 +247,13 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
       mp.n_seq = nc;
       mp.N = L;
       mp.D = D;
-      XNRS_TRY(launch_mean_pool(mp, stream));
+      {
+        ProfScope ps(4, 2.0 * rows * (double)D, stream);
+        XNRS_TRY(launch_mean_pool(mp, stream));
+      }
     }
     if (head) {
+      ProfScope ps(5, 2.0 * nc * ((double)D * E + (double)E * E), stream);
       XNRS_TRY(launch_gemm_f32(gemm1(pb, nullptr, 0, D, head->w0, head->b0, hb, E, nc, E, D, XNRS_ACT_RELU), stream));
       XNRS_TRY(launch_gemm_f32(gemm1(hb, nullptr, 0, E, head->w2, head->b2, y + c0 * (int64_t)E, E, nc, E, E,
                                      XNRS_ACT_NONE),
@@ -291,6 +344,41 @@ int32_t xnrs_user_encoder_fwd(const float* x, const float* m, int64_t B, int32_t
                               float* a_out, void* ws, size_t ws_bytes, void* stream) {
   return seq_encode(x, m, nullptr, B, H, E, att, true, pool_kind, pool, head, y, a_out, nullptr, 0, ws, ws_bytes,
                     (hipStream_t)stream);
+}
+
+int32_t xnrs_profile_enable(uint32_t stage_mask) {
+  for (auto& r : g_prof) {
+    (void)hipEventDestroy(r.beg);
+    (void)hipEventDestroy(r.end);
+  }
+  g_prof.clear();
+  g_prof_mask = stage_mask;
+  return XNRS_OK;
+}
+
+int32_t xnrs_profile_read(double* ms, int64_t* launches, double* flops) {
+  if (!ms || !launches || !flops) return XNRS_EINVAL;
+  for (int i = 0; i < XNRS_PROFILE_STAGES; ++i) {
+    ms[i] = 0.0;
+    launches[i] = 0;
+    flops[i] = 0.0;
+  }
+  int32_t rc = XNRS_OK;
+  for (auto& r : g_prof) {
+    float t = 0.f;
+    hipError_t e = hipEventSynchronize(r.end);
+    if (e == hipSuccess) e = hipEventElapsedTime(&t, r.beg, r.end);
+    if (e != hipSuccess) rc = (int32_t)e;
+    else {
+      ms[r.stage] += t;
+      launches[r.stage] += 1;
+      flops[r.stage] += r.flops;
+    }
+    (void)hipEventDestroy(r.beg);
+    (void)hipEventDestroy(r.end);
+  }
+  g_prof.clear();
+  return rc;
 }
 
 int32_t xnrs_dot_scoring_fwd(const float* u, const float* c, float* r, int64_t B, int32_t C, int32_t E, int32_t normalize,

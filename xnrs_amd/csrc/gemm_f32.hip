@@ -1,38 +1,53 @@
-// fp32 Linear on the CDNA4 matrix cores:  C = act(A . W^T + bias)
+// fp32 GEMM on the CDNA4 matrix cores.
 //
-// Replaces nn.Linear as used by the reference hot path (xnrs/models/components/layers.py:60,
-// 128-130,154; news_encoding.py:27-31).  Numerics: v_mfma_f32_32x32x2_f32 is an exact fp32 fmaf
-// chain (no TF32/xf32 on gfx950), so results differ from torch-CPU only by summation order.
+//   forward   C = act(A . W^T + bias)            A row-major [M,K], W = nn.Linear weight [N,K]     (ROW, WT)
+//   backward  dX = (dY . W) (*) f'(aux) [+ C]    A = dY [M,N'] row-major, B = W as [K'=N'][N=K_in] (ROW, KN)
+//             dW = dY^T . X                      A = dY read k-major (A^T[k=m][i]), B = X [k=m][n]  (COL, KN)
+//
+// Replaces nn.Linear (and its autograd) as used by the reference hot path
+// (xnrs/models/components/layers.py:60,128-130,154; news_encoding.py:27-31).  Numerics:
+// v_mfma_f32_32x32x2_f32 is an exact fp32 fmaf chain (no TF32/xf32 on gfx950), so results differ from
+// torch-CPU only by summation order.
 //
 // Design (gfx950, 64-wide waves):
 //   * workgroup = 256 threads = 4 waves in a 2x2 grid; wave tile (32*TM)x(32*TN), i.e. the block
 //     tile is (64*TM)x(64*TN); BK = 32.
-//   * both operands are K-contiguous (x rows, nn.Linear weight rows), so a lane fetches 4
-//     consecutive k with ONE ds_read_b128 and feeds 4 MFMA steps from it: MFMA step j of an
-//     8-wide k group uses k = 4*(lane>>5) + j for A and B alike (any bijection of k is legal as
-//     long as A and B agree).  Per 8 k: TM+TN LDS reads vs 4*TM*TN MFMAs (64 cycles each).
-//   * LDS rows padded to 36 floats: the 16-lane groups of ds_read_b128 then hit 64 distinct banks.
+//   * k-contiguous operands (ROW / WT): a lane fetches 4 consecutive k with ONE ds_read_b128 and feeds
+//     4 MFMA steps from it: MFMA step j of an 8-wide k group uses k = 4*(lane>>5) + j for A and B
+//     alike (any bijection of k is legal as long as A and B agree).  LDS rows padded to 36 floats:
+//     the 16-lane groups of ds_read_b128 then hit 64 distinct banks.
+//   * k-major operands (COL / KN): LDS image [k][i] (rows padded by 4), fragments are 4 ds_read_b32
+//     with the 32 lanes of a half-wave on 32 consecutive floats (conflict-free).
+//     Per 8 k: TM+TN b128 reads (or 4x as many b32) vs 4*TM*TN MFMAs of 64 cycles each.
 //   * register-staged double buffering (issue global loads for tile t+1, compute tile t, then write
-//     LDS) with one barrier per K tile; 2 workgroups/CU co-reside (73.7 KB LDS each).
-//   * optional row gather on A (device-resident news-token table + ids: SURVEY.md section 8 a0) folded into
-//     the per-thread row pointers, so gathered rows are still read as full 128-B lines.
+//     LDS) with one barrier per K tile; 2 workgroups/CU co-reside (<= 73.7 KB LDS each).
+//   * optional row gather on the rows of a ROW-layout A / KN-layout B (device-resident news-token
+//     table + ids: SURVEY.md section 8 a0) folded into the per-thread row pointers, so gathered rows are still
+//     read as full 128-B lines.
 //   * XCD-aware block order: the 8 XCDs each walk a contiguous range of tiles with the N tiles of
 //     one M tile adjacent, so an A tile is fetched into one L2 only.
+//   * split-K (dW: the contraction is the token-row count, the output is a small weight matrix):
+//     each k-slice writes its own fp32 slab; a second kernel sums the slabs in a fixed order
+//     (bitwise reproducible, no float atomics).
 #include "kernels.h"
 
 namespace xnrs {
 
 constexpr int BK = 32;
-constexpr int LDS_LD = BK + 4;  // padded row length in floats (144 B, 16-B aligned)
+constexpr int LDK = BK + 4;  // padded row of a k-contiguous LDS tile (144 B, 16-B aligned)
 
-template <int TM, int TN, bool VEC>
+template <int TM, int TN, bool A_COL, bool B_KN, bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a, int m_tiles, int n_tiles_seg) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
-  constexpr int AR = BM / 32, BR = BN / 32;  // rows per thread per operand tile
-  __shared__ __attribute__((aligned(16))) float As[2][BM][LDS_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDS_LD];
+  constexpr int AR = BM / 32, BR = BN / 32;  // 16-byte chunks per thread per operand tile
+  constexpr int LDA = A_COL ? (BM + 4) : LDK;
+  constexpr int LDB = B_KN ? (BN + 4) : LDK;
+  constexpr int A_SZ = A_COL ? BK * LDA : BM * LDA;
+  constexpr int B_SZ = B_KN ? BK * LDB : BN * LDB;
+  __shared__ __attribute__((aligned(16))) float As[2][A_SZ];
+  __shared__ __attribute__((aligned(16))) float Bs[2][B_SZ];
 
-  // ---- XCD-aware tile order (bijective for any grid size)
+  // ---- XCD-aware tile order (bijective for any grid size); blockIdx.y = k slice
   const int nwg = gridDim.x;
   const int bid = blockIdx.x;
   const int xcd = bid & 7;
@@ -46,6 +61,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a, int m_tile
   const int64_t m0 = (int64_t)mt * BM;
   const int n0 = nts * BN;  // column inside the segment
 
+  const int64_t kbeg = (int64_t)blockIdx.y * a.k_per_split;
+  const int64_t kend = (kbeg + a.k_per_split < a.K) ? kbeg + a.k_per_split : a.K;
+
   const float* __restrict__ W = a.W[seg];
   const float* __restrict__ bias = a.bias[seg];
 
@@ -53,69 +71,130 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a, int m_tile
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int lc = tid & 7;   // 16-byte chunk inside the 32-float k tile
-  const int lr = tid >> 3;  // 0..31
 
-  // ---- per-thread source rows
+  // ---- staging maps
+  // k-contiguous tile: chunk lc (4 floats of k) of row lr + 32*i
+  const int lc = tid & 7, lr = tid >> 3;
+  // k-major tile: chunk (4 floats along i) cA of k-row kA + KROWS*i
+  constexpr int CHA = BM / 4, KRA = 256 / CHA;  // chunks per k-row, k-rows per pass
+  constexpr int CHB = BN / 4, KRB = 256 / CHB;
+  const int cA = tid % CHA, kA = tid / CHA;
+  const int cB = tid % CHB, kB = tid / CHB;
+
   const float* pa[AR];
   const float* pb[BR];
+  if (!A_COL) {
 #pragma unroll
-  for (int i = 0; i < AR; ++i) {
-    const int64_t gr = m0 + lr + 32 * i;
-    if (gr < a.M) {
-      int64_t src = gr;
-      if (a.gather_ids) {
-        const int64_t n = gr / a.gather_S;
-        src = (int64_t)a.gather_ids[n] * a.gather_S + (gr - n * a.gather_S);
-      }
-      pa[i] = a.A + src * a.lda + 4 * lc;
-    } else {
+    for (int i = 0; i < AR; ++i) {
+      const int64_t gr = m0 + lr + 32 * i;
       pa[i] = nullptr;
+      if (gr < a.M) {
+        int64_t src = gr;
+        if (a.gather_ids) {
+          const int64_t n = gr / a.gather_S;
+          src = (int64_t)a.gather_ids[n] * a.gather_S + (gr - n * a.gather_S);
+        }
+        pa[i] = a.A + src * a.lda + 4 * lc;
+      }
     }
   }
+  if (!B_KN) {
 #pragma unroll
-  for (int i = 0; i < BR; ++i) {
-    const int col = n0 + lr + 32 * i;
-    pb[i] = (col < a.Nseg) ? (W + (int64_t)col * a.ldw + 4 * lc) : nullptr;
+    for (int i = 0; i < BR; ++i) {
+      const int col = n0 + lr + 32 * i;
+      pb[i] = (col < a.Nseg) ? (W + (int64_t)col * a.ldw + 4 * lc) : nullptr;
+    }
   }
 
   f32x4 ra[AR], rb[BR];
-  auto gload = [&](int k0) {
-    const int k = k0 + 4 * lc;
+  auto gload = [&](int64_t k0) {
+    if (!A_COL) {
+      const int64_t k = k0 + 4 * lc;
 #pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (pa[i]) {
-        if (VEC) {
-          if (k < a.K) v = *reinterpret_cast<const f32x4*>(pa[i] + k0);
-        } else {
+      for (int i = 0; i < AR; ++i) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (pa[i]) {
+          if (VEC) {
+            if (k < kend) v = *reinterpret_cast<const f32x4*>(pa[i] + k0);
+          } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (k + e < a.K) v[e] = pa[i][k0 + e];
+            for (int e = 0; e < 4; ++e)
+              if (k + e < kend) v[e] = pa[i][k0 + e];
+          }
         }
+        ra[i] = v;
       }
-      ra[i] = v;
+    } else {
+      const int64_t mi = m0 + 4 * cA;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const int64_t k = k0 + kA + KRA * i;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < kend) {
+          const float* p = a.A + k * a.lda + mi;
+          if (VEC) {
+            if (mi < a.M) v = *reinterpret_cast<const f32x4*>(p);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (mi + e < a.M) v[e] = p[e];
+          }
+        }
+        ra[i] = v;
+      }
     }
+    if (!B_KN) {
+      const int64_t k = k0 + 4 * lc;
 #pragma unroll
-    for (int i = 0; i < BR; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (pb[i]) {
-        if (VEC) {
-          if (k < a.K) v = *reinterpret_cast<const f32x4*>(pb[i] + k0);
-        } else {
+      for (int i = 0; i < BR; ++i) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (pb[i]) {
+          if (VEC) {
+            if (k < kend) v = *reinterpret_cast<const f32x4*>(pb[i] + k0);
+          } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (k + e < a.K) v[e] = pb[i][k0 + e];
+            for (int e = 0; e < 4; ++e)
+              if (k + e < kend) v[e] = pb[i][k0 + e];
+          }
         }
+        rb[i] = v;
       }
-      rb[i] = v;
+    } else {
+      const int ni = n0 + 4 * cB;
+#pragma unroll
+      for (int i = 0; i < BR; ++i) {
+        const int64_t k = k0 + kB + KRB * i;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < kend) {
+          int64_t src = k;
+          if (a.b_gather_ids) {
+            const int64_t n = k / a.b_gather_S;
+            src = (int64_t)a.b_gather_ids[n] * a.b_gather_S + (k - n * a.b_gather_S);
+          }
+          const float* p = W + src * a.ldw + ni;
+          if (VEC) {
+            if (ni < a.Nseg) v = *reinterpret_cast<const f32x4*>(p);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (ni + e < a.Nseg) v[e] = p[e];
+          }
+        }
+        rb[i] = v;
+      }
     }
   };
   auto sstore = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(&As[buf][lr + 32 * i][4 * lc]) = ra[i];
+    for (int i = 0; i < AR; ++i) {
+      if (!A_COL) *reinterpret_cast<f32x4*>(&As[buf][(lr + 32 * i) * LDA + 4 * lc]) = ra[i];
+      else *reinterpret_cast<f32x4*>(&As[buf][(kA + KRA * i) * LDA + 4 * cA]) = ra[i];
+    }
 #pragma unroll
-    for (int i = 0; i < BR; ++i) *reinterpret_cast<f32x4*>(&Bs[buf][lr + 32 * i][4 * lc]) = rb[i];
+    for (int i = 0; i < BR; ++i) {
+      if (!B_KN) *reinterpret_cast<f32x4*>(&Bs[buf][(lr + 32 * i) * LDB + 4 * lc]) = rb[i];
+      else *reinterpret_cast<f32x4*>(&Bs[buf][(kB + KRB * i) * LDB + 4 * cB]) = rb[i];
+    }
   };
 
   f32x16 acc[TM][TN];
@@ -126,25 +205,41 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a, int m_tile
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int frow = lane & 31;        // row of the 32x32 operand tile this lane feeds
-  const int fk = (lane >> 5) * 4;    // k offset inside an 8-wide k group
+  const int frow = lane & 31;      // row of the 32x32 operand tile this lane feeds
+  const int fk = (lane >> 5) * 4;  // k offset inside an 8-wide k group
   const int a_row0 = wm * 32 * TM + frow;
   const int b_row0 = wn * 32 * TN + frow;
 
-  const int nk = (a.K + BK - 1) / BK;
-  gload(0);
-  sstore(0);
+  const int nk = (int)((kend - kbeg + BK - 1) / BK);
+  if (nk > 0) {
+    gload(kbeg);
+    sstore(0);
+  }
   __syncthreads();
   for (int t = 0; t < nk; ++t) {
     const int buf = t & 1;
-    if (t + 1 < nk) gload((t + 1) * BK);
+    if (t + 1 < nk) gload(kbeg + (int64_t)(t + 1) * BK);
 #pragma unroll
     for (int kq = 0; kq < BK / 8; ++kq) {
       f32x4 fa[TM], fb[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(&As[buf][a_row0 + 32 * i][kq * 8 + fk]);
+      for (int i = 0; i < TM; ++i) {
+        if (!A_COL) {
+          fa[i] = *reinterpret_cast<const f32x4*>(&As[buf][(a_row0 + 32 * i) * LDA + kq * 8 + fk]);
+        } else {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(&Bs[buf][b_row0 + 32 * j][kq * 8 + fk]);
+          for (int e = 0; e < 4; ++e) fa[i][e] = As[buf][(kq * 8 + fk + e) * LDA + a_row0 + 32 * i];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (!B_KN) {
+          fb[j] = *reinterpret_cast<const f32x4*>(&Bs[buf][(b_row0 + 32 * j) * LDB + kq * 8 + fk]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) fb[j][e] = Bs[buf][(kq * 8 + fk + e) * LDB + b_row0 + 32 * j];
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -160,50 +255,65 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a, int m_tile
   // ---- epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
   const int ccol = lane & 31;
   const int crow = 4 * (lane >> 5);
+  const bool split = gridDim.y > 1;
+  float* Cout = split ? a.slabs + (int64_t)blockIdx.y * a.slab_stride : a.C;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + wn * 32 * TN + 32 * j + ccol;
     if (col >= a.Nseg) continue;
-    const float bv = bias ? bias[col] : 0.f;
-    float* cbase = a.C + (int64_t)seg * a.Nseg + col;
+    const float bv = (bias && !split) ? bias[col] : 0.f;
+    const int64_t coff = (int64_t)seg * a.Nseg + col;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int64_t row = m0 + wm * 32 * TM + 32 * i + (e & 3) + 8 * (e >> 2) + crow;
         if (row < a.M) {
-          float v = acc[i][j][e] + bv;
-          if (a.act == 1) v = fmaxf(v, 0.f);
-          else if (a.act == 2) v = tanhf(v);
-          cbase[row * a.ldc] = v;
+          float v = acc[i][j][e];
+          if (!split) {
+            v += bv;
+            if (a.act == 1) v = fmaxf(v, 0.f);
+            else if (a.act == 2) v = tanhf(v);
+            if (a.aux_mode) {
+              const float x = a.aux[row * a.ldaux + coff];
+              v *= (a.aux_mode == 1) ? (1.f - x * x) : (x > 0.f ? 1.f : 0.f);
+            }
+            if (a.accumulate) v += Cout[row * a.ldc + coff];
+          }
+          Cout[row * a.ldc + coff] = v;
         }
       }
     }
   }
 }
 
-template <int TM, int TN>
-static hipError_t launch_cfg(const GemmArgs& a, bool vec, hipStream_t stream) {
+// C (+)= sum_s slabs[s]  (fixed order -> bitwise reproducible)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, int64_t slab_stride, int nsplit, float* C,
+                                                             int64_t n, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float v = accumulate ? C[i] : 0.f;
+  for (int s = 0; s < nsplit; ++s) v += slabs[(int64_t)s * slab_stride + i];
+  C[i] = v;
+}
+
+template <int TM, int TN, bool A_COL, bool B_KN>
+static hipError_t launch_cfg(const GemmArgs& a, bool vec, int nsplit, hipStream_t stream) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   const int64_t m_tiles = (a.M + BM - 1) / BM;
   const int n_tiles_seg = (a.Nseg + BN - 1) / BN;
   const int64_t grid = m_tiles * n_tiles_seg * a.nseg;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  const dim3 g((unsigned)grid, (unsigned)nsplit);
   if (vec)
-    hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, true>), dim3((unsigned)grid), dim3(256), 0, stream, a, (int)m_tiles,
-                       n_tiles_seg);
+    hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, A_COL, B_KN, true>), g, dim3(256), 0, stream, a, (int)m_tiles, n_tiles_seg);
   else
-    hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, false>), dim3((unsigned)grid), dim3(256), 0, stream, a, (int)m_tiles,
-                       n_tiles_seg);
+    hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, A_COL, B_KN, false>), g, dim3(256), 0, stream, a, (int)m_tiles, n_tiles_seg);
   return hipGetLastError();
 }
 
-hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t stream) {
-  if (a.M <= 0 || a.Nseg <= 0 || a.K <= 0) return hipSuccess;
-  // 16-byte vector loads need K-contiguous rows on 16-B boundaries
-  bool vec = (a.K % 4 == 0) && (a.lda % 4 == 0) && (a.ldw % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0);
-  for (int s = 0; s < a.nseg; ++s) vec = vec && ((reinterpret_cast<uintptr_t>(a.W[s]) & 15) == 0);
-
+template <bool A_COL, bool B_KN>
+static hipError_t launch_layout(const GemmArgs& a, bool vec, int nsplit, hipStream_t stream) {
   // pick the tile with the least estimated time: rounds of co-resident workgroups x padded tile work
   // (2 workgroups/CU x 256 CUs per round); bigger tiles have slightly better MFMA duty.
   const int cand[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
@@ -212,7 +322,7 @@ hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t stream) {
   double best_t = 1e300;
   for (int c = 0; c < 4; ++c) {
     const int64_t bm = 64 * cand[c][0], bn = 64 * cand[c][1];
-    const int64_t wgs = ((a.M + bm - 1) / bm) * ((a.Nseg + bn - 1) / bn) * a.nseg;
+    const int64_t wgs = ((a.M + bm - 1) / bm) * ((a.Nseg + bn - 1) / bn) * a.nseg * nsplit;
     const double rounds = (double)((wgs + 511) / 512);
     const double t = rounds * (double)(bm * bn) / eff[c];
     if (t < best_t * 0.999) {
@@ -221,11 +331,65 @@ hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t stream) {
     }
   }
   switch (best) {
-    case 0: return launch_cfg<2, 2>(a, vec, stream);
-    case 1: return launch_cfg<2, 1>(a, vec, stream);
-    case 2: return launch_cfg<1, 2>(a, vec, stream);
-    default: return launch_cfg<1, 1>(a, vec, stream);
+    case 0: return launch_cfg<2, 2, A_COL, B_KN>(a, vec, nsplit, stream);
+    case 1: return launch_cfg<2, 1, A_COL, B_KN>(a, vec, nsplit, stream);
+    case 2: return launch_cfg<1, 2, A_COL, B_KN>(a, vec, nsplit, stream);
+    default: return launch_cfg<1, 1, A_COL, B_KN>(a, vec, nsplit, stream);
   }
+}
+
+size_t gemm_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  const int ns = gemm_pick_splits(M, N, K);
+  return ns > 1 ? (size_t)ns * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+int gemm_pick_splits(int64_t M, int64_t N, int64_t K) {
+  // aim for ~1024 workgroups of 128x128 and at least 256 contraction steps per slice
+  const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  int64_t ns = (1024 + tiles - 1) / tiles;
+  const int64_t max_by_k = K / 256;
+  if (ns > max_by_k) ns = max_by_k;
+  if (ns > 64) ns = 64;
+  if (ns < 1) ns = 1;
+  return (int)ns;
+}
+
+hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t stream) {
+  GemmArgs a = a_in;
+  if (a.M <= 0 || a.Nseg <= 0) return hipSuccess;
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  // 16-byte vector loads need the contiguous dimension of each operand on 16-B boundaries
+  bool vec = (a.lda % 4 == 0) && (a.ldw % 4 == 0) && al16(a.A);
+  vec = vec && (a.a_col ? (a.M % 4 == 0) : (a.K % 4 == 0));
+  vec = vec && (a.b_kn ? (a.Nseg % 4 == 0) : (a.K % 4 == 0));
+  for (int s = 0; s < a.nseg; ++s) vec = vec && al16(a.W[s]);
+
+  int nsplit = 1;
+  if (a.slabs && a.nsplit > 1) {
+    nsplit = a.nsplit;
+    const int64_t per = ((a.K + nsplit - 1) / nsplit + BK - 1) / BK * BK;  // BK-aligned slices
+    a.k_per_split = per;
+    nsplit = (int)((a.K + per - 1) / per);
+    a.slab_stride = a.M * a.ldc;
+    if (a.nseg != 1 || a.ldc != a.Nseg) return hipErrorInvalidValue;
+  }
+  if (nsplit <= 1) {
+    nsplit = 1;
+    a.k_per_split = a.K > 0 ? a.K : 1;
+  }
+  hipError_t e;
+  if (!a.a_col && !a.b_kn) e = launch_layout<false, false>(a, vec, nsplit, stream);
+  else if (!a.a_col && a.b_kn) e = launch_layout<false, true>(a, vec, nsplit, stream);
+  else if (a.a_col && a.b_kn) e = launch_layout<true, true>(a, vec, nsplit, stream);
+  else return hipErrorInvalidValue;
+  if (e != hipSuccess) return e;
+  if (nsplit > 1) {
+    const int64_t n = a.M * a.ldc;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a.slabs, a.slab_stride,
+                       nsplit, a.C, n, a.accumulate);
+    e = hipGetLastError();
+  }
+  return e;
 }
 
 }  // namespace xnrs

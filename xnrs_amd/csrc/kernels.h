@@ -15,20 +15,35 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // tensors, as the reference's state_dict requires).
 struct GemmArgs {
   const float* A;
-  const int32_t* gather_ids;  // nullable: logical row m -> table row ids[m/gather_S]*gather_S + m%gather_S
+  int32_t a_col;              // 0: A[m][k] row-major (lda = row stride); 1: A given k-major, A^T[k][m] (lda = k stride)
+  const int32_t* gather_ids;  // nullable (ROW A only): logical row m -> table row ids[m/gather_S]*gather_S + m%gather_S
   int32_t gather_S;
-  int64_t lda;  // row stride of A in floats
+  int64_t lda;
   const float* W[3];
   const float* bias[3];  // nullable each
+  int32_t b_kn;          // 0: W[n][k] (nn.Linear weight, ldw = row stride); 1: B[k][n] k-major (ldw = k stride)
+  const int32_t* b_gather_ids;  // nullable (KN B only): k-row gather, same rule as gather_ids
+  int32_t b_gather_S;
   int32_t nseg;
   int32_t Nseg;  // columns per segment
-  int64_t ldw;   // row stride of every W in floats
+  int64_t ldw;
   float* C;
   int64_t ldc;
   int64_t M;
-  int32_t K;
-  int32_t act;
+  int64_t K;
+  int32_t act;         // 0 none, 1 relu, 2 tanh (applied after bias)
+  const float* aux;    // nullable: elementwise factor source with the shape of C (ldaux)
+  int64_t ldaux;
+  int32_t aux_mode;    // 0 none; 1: C *= (1 - aux^2) (tanh'); 2: C *= (aux > 0) (relu')
+  int32_t accumulate;  // 1: C += result
+  // split-K (deterministic slabs + ordered reduce); set by the caller via slabs/nsplit
+  float* slabs;        // nullable workspace of nsplit * M * ldc floats
+  int32_t nsplit;
+  int64_t k_per_split;  // filled in by the launcher
+  int64_t slab_stride;  // filled in by the launcher
 };
+int gemm_pick_splits(int64_t M, int64_t N, int64_t K);
+size_t gemm_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
 hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t stream);
 
 // ---------------------------------------------------------------- attention core (QK^T, row mask, softmax, PV)

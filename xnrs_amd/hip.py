@@ -23,8 +23,9 @@ SYMBOLS = (
     "xnrs_abi_version", "xnrs_error_string", "xnrs_linear_fwd", "xnrs_mha_workspace_bytes", "xnrs_mha_fwd",
     "xnrs_additive_workspace_bytes", "xnrs_additive_attention_fwd", "xnrs_masked_mean_fwd", "xnrs_collapse_mask",
     "xnrs_text_encoder_workspace_bytes", "xnrs_text_encoder_fwd", "xnrs_user_encoder_workspace_bytes",
-    "xnrs_user_encoder_fwd", "xnrs_dot_scoring_fwd",
+    "xnrs_user_encoder_fwd", "xnrs_dot_scoring_fwd", "xnrs_profile_enable", "xnrs_profile_read",
 )
+PROFILE_STAGES = ("qkv_gemm", "attention_core", "out_gemm", "fc1_tanh_gemm", "pool", "head_gemms")
 
 
 class XnrsHipError(RuntimeError):
@@ -88,6 +89,10 @@ def lib():
                                         C.POINTER(HeadParams), p, p, p, sz, p]
     l.xnrs_dot_scoring_fwd.restype = i32
     l.xnrs_dot_scoring_fwd.argtypes = [p, p, p, i64, i32, i32, i32, p]
+    l.xnrs_profile_enable.restype = i32
+    l.xnrs_profile_enable.argtypes = [C.c_uint32]
+    l.xnrs_profile_read.restype = i32
+    l.xnrs_profile_read.argtypes = [p, p, p]
     if l.xnrs_abi_version() != 1:
         raise XnrsHipError("libxnrs_hip.so ABI version mismatch; rebuild it")
     _lib = l
@@ -102,6 +107,18 @@ def check(rc: int, what: str):
         # same exception type as the reference's failing .view() (layers.py:111,133)
         raise RuntimeError(f"{what}: {msg}")
     raise XnrsHipError(f"{what}: {msg} (code {rc})")
+
+
+def profile_enable(stage_mask: int):
+    check(lib().xnrs_profile_enable(stage_mask), "xnrs_profile_enable")
+
+
+def profile_read():
+    """-> {stage: (ms, launches, flops)} of the launches recorded since profile_enable()."""
+    n = len(PROFILE_STAGES)
+    ms, ln, fl = (C.c_double * n)(), (C.c_int64 * n)(), (C.c_double * n)()
+    check(lib().xnrs_profile_read(ms, ln, fl), "xnrs_profile_read")
+    return {PROFILE_STAGES[i]: (ms[i], ln[i], fl[i]) for i in range(n)}
 
 
 # ---------------------------------------------------------------------------------- tensor plumbing
