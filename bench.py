@@ -117,10 +117,22 @@ def timed(fn, steps, warmup, dist_on):
     return dt
 
 
+def usable_cores():
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(w, sd, sample_B=32, reps=3):
     """Oracle (torch CPU fp32 restatement, pinned to the reference by tests/golden) on the host cores."""
     from oracle import xnrs_oracle as O
-    threads = os.cpu_count() or 1
+    threads = usable_cores()
     torch.set_num_threads(threads)
     rng_batch = synth.make_batch(77, sample_B, w["H"], w["C"], w["S"], w["D"], min_len=5)
     hist = rng_batch["user_features"]["history"]["title_emb"]
@@ -137,7 +149,7 @@ def cpu_baseline(w, sd, sample_B=32, reps=3):
                        f"{reps} timed passes after 1 warm-up, {dt:.2f} s/pass"), r
 
 
-def news_only_extra(device, steps=5, warmup=2):
+def news_only_extra(device, steps=20, warmup=10):
     """BASELINE configs[1]: NRMS news encoder only, 1024 news, at the reference-valid stand-ins of the
     impossible 'd=300, 16 heads' (SURVEY.md finding 2) and at the shipped shape."""
     out = {}
@@ -149,6 +161,10 @@ def news_only_extra(device, steps=5, warmup=2):
         x, m = synth.device_tokens(gen, 1024, S, D, device)
         x, m = x.reshape(1, 1024, S, D), m.reshape(1, 1024, S, 1)
         fn = lambda: model.news_encoder((x, m))  # noqa: E731
+        t_end = time.perf_counter() + 0.3  # let the clocks ramp after the idle CPU phase
+        while time.perf_counter() < t_end:
+            fn()
+            torch.cuda.synchronize()
         dt = timed(fn, steps, warmup, False) / steps
         fl = 1024 * news_flops(S, D, 256, w["E"])
         out[name] = dict(news_per_s=1024 / dt, ms=dt * 1e3, tflops=fl / dt / 1e12,

@@ -30,7 +30,7 @@ struct Plan {
 // workspace carve for one chunk; every region 256-B aligned
 Plan make_plan(int64_t n_seq, int L, int D, int A, int E, bool att, bool additive, bool head, bool pooled, int64_t chunk) {
   Plan p{};
-  if (chunk <= 0) chunk = (65536 + L - 1) / L;  // ~64k rows per pass
+  if (chunk <= 0) chunk = 65536 / L;  // <= 64k token rows per pass: 512 full 128-row GEMM tiles (whole rounds of workgroups)
   if (chunk > n_seq) chunk = n_seq;
   if (chunk < 1) chunk = 1;
   p.chunk = chunk;
@@ -118,8 +118,8 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
                    const xnrs_mha_params* att, bool pooled, int pool_kind, const xnrs_additive_params* pool,
                    const xnrs_head_params* head, float* y, float* a_out, float* hm, int64_t chunk, void* ws,
                    size_t ws_bytes, hipStream_t stream) {
-  if (n_seq < 0 || L <= 0 || D <= 0 || !x || !y) return XNRS_EINVAL;
   if (n_seq == 0) return XNRS_OK;
+  if (n_seq < 0 || L <= 0 || D <= 0 || !x || !y) return XNRS_EINVAL;
   if (att) {
     if (att->n_heads <= 0 || !att->wq || !att->wk || !att->wv || !att->wo) return XNRS_EINVAL;
     if (D % att->n_heads != 0) return XNRS_EHEADS;
@@ -328,6 +328,7 @@ int32_t xnrs_text_encoder_fwd(const float* x, const float* m, const int32_t* ids
                               const xnrs_mha_params* att, int32_t pool_kind, const xnrs_additive_params* pool,
                               const xnrs_head_params* head, float* y, float* hm, int64_t chunk, void* ws, size_t ws_bytes,
                               void* stream) {
+  if (n_news == 0) return XNRS_OK;
   if (!m) return XNRS_EINVAL;  // TextEncoder always receives a token mask (news_encoding.py:41-50)
   int32_t rc = seq_encode(x, m, ids, n_news, S, D, att, true, pool_kind, pool, head, y, nullptr, hm, chunk, ws, ws_bytes,
                           (hipStream_t)stream);

@@ -61,8 +61,47 @@ struct MhaCoreArgs {
   int32_t scaled;
   float dropout_p;
   uint64_t seed;
+  float* stats;  // nullable: per (seq, head, query) softmax row statistics {max, sum} kept for the backward
 };
 hipError_t launch_mha_core(const MhaCoreArgs& a, hipStream_t stream);
+
+// backward of the attention core: recomputes P from Q, K and the saved row statistics
+struct MhaBwdArgs {
+  const float* q;
+  const float* k;
+  const float* v;
+  int64_t ld;
+  const float* mask;
+  const int32_t* mask_gather_ids;
+  const float* o;     // forward output (concat heads), [rows, ldo]
+  int64_t ldo;
+  const float* d_o;   // gradient w.r.t. the forward output, [rows, lddo]
+  int64_t lddo;
+  const float* stats; // from the forward
+  float* delta;       // scratch [n_seq*n_heads*S]: rowsum(dO * O) per head
+  float* dq;          // gradients, same addressing rule as q/k/v with row stride ldd
+  float* dk;
+  float* dv;
+  int64_t ldd;
+  int64_t n_seq;
+  int32_t S, n_heads, d_k;
+  int32_t scaled;
+  float dropout_p;
+  uint64_t seed;
+};
+hipError_t launch_mha_bwd(const MhaBwdArgs& a, hipStream_t stream);
+
+// counter-based RNG for attention dropout (training mode only): splitmix64 finaliser on
+// (seed, element index) -> uniform [0,1).  Parity with torch's CPU Philox stream is impossible
+// (SURVEY.md section 7 "hard parts"); only the distribution matters.  Forward and backward call this with
+// the same (seed, index) so the mask is recomputed, never stored.
+__device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
 
 // ---------------------------------------------------------------- pooling / scoring
 struct AdditivePoolArgs {
@@ -94,6 +133,31 @@ struct MeanPoolArgs {
   int32_t N, D;
 };
 hipError_t launch_mean_pool(const MeanPoolArgs& a, hipStream_t stream);
+
+// ---------------------------------------------------------------- backward of pooling / scoring
+struct AdditivePoolBwdArgs {
+  const float* dp;   // [n_seq, D] gradient of the pooled vector
+  const float* x;    // value rows (or table)
+  int64_t ldx;
+  const int32_t* x_gather_ids;
+  const float* a;    // [n_seq*N] attention weights from the forward
+  const float* t;    // [n_seq*N, A] tanh(fc1 x) from the forward
+  const float* w2;   // [A]
+  float* dx;         // nullable [n_seq*N, lddx] = a_i * dp
+  int64_t lddx;
+  float* dpre;       // [n_seq*N, A] gradient at the fc1 pre-activation
+  float* de;         // [n_seq*N] gradient at the fc2 output (score)
+  int64_t n_seq;
+  int32_t N, D, A;
+};
+hipError_t launch_additive_pool_bwd(const AdditivePoolBwdArgs& a, hipStream_t stream);
+hipError_t launch_mean_pool_bwd(const float* dy, const float* mask, const int32_t* mask_ids, float* dx, int64_t lddx,
+                                int64_t n_seq, int32_t N, int32_t D, hipStream_t stream);
+size_t colsum_workspace_bytes(int N);
+hipError_t launch_colsum(const float* X, int64_t ldx, const float* w, int64_t M, int N, float* out, float* partial,
+                         hipStream_t stream);
+hipError_t launch_dot_scoring_bwd(const float* u, const float* c, const float* dr, float* du, float* dc, int64_t B, int32_t C,
+                                  int32_t E, hipStream_t stream);
 
 hipError_t launch_collapse_mask(const float* m, const int32_t* gather_ids, float* hm, int64_t n_rows, int32_t S,
                                 hipStream_t stream);

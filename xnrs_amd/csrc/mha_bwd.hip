@@ -1,0 +1,321 @@
+// Backward of the attention core (autograd of xnrs/models/components/layers.py:138-151).
+//
+//   P  = softmax(rowmask(Q K^T / sqrt(dk)))          (recomputed from Q, K and the saved row {max,sum})
+//   Pd = dropout(P)                                   (mask recomputed from the counter RNG)
+//   O  = Pd V
+//   dV = Pd^T dO ;  dPd = dO V^T ;  dP = dropout'(dPd)
+//   dS = P * (dP - delta),  delta = rowsum(dO * O)    (softmax backward, flash-attention form)
+//   dS = 0 on rows with mask == 0 (masked_fill blocks the gradient), dS /= sqrt(dk)
+//   dQ = dS K ;  dK = dS^T Q
+//
+// Three kernels, all fp32 MFMA 16x16x4, no LDS, no atomics (bitwise reproducible):
+//   delta : thread per (row, head)
+//   dq    : wave per (seq, head, 16-query tile); queries on the lanes' column index (the forward's
+//           layout), so dS is directly the B operand of dQ^T = K^T dS^T.
+//   dkdv  : wave per (seq, head, 16-key tile); keys on the lanes' column index, loops over the query
+//           tiles and keeps dK^T / dV^T of its 16 keys in accumulators, so nothing is summed across
+//           waves.  Pd and dS are directly the B operands of dV^T = dO^T Pd and dK^T = Q^T dS.
+#include "kernels.h"
+
+namespace xnrs {
+
+constexpr int MAX_FT = 8;  // d_k <= 128
+
+__global__ __launch_bounds__(256) void mha_delta_kernel(MhaBwdArgs a, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  // i = (seq*h + hd)*S + query
+  const int query = (int)(i % a.S);
+  const int64_t sh = i / a.S;
+  const int hd = (int)(sh % a.n_heads);
+  const int64_t seq = sh / a.n_heads;
+  const int64_t row = seq * a.S + query;
+  const float* o = a.o + row * a.ldo + hd * a.d_k;
+  const float* d = a.d_o + row * a.lddo + hd * a.d_k;
+  float acc = 0.f;
+  for (int e = 0; e < a.d_k; ++e) acc = fmaf(o[e], d[e], acc);
+  a.delta[i] = acc;
+}
+
+__device__ __forceinline__ f32x4 load4(const float* p, int f0, int lim, bool vec) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (vec) {
+    if (f0 < lim) v = *reinterpret_cast<const f32x4*>(p + f0);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (f0 + e < lim) v[e] = p[f0 + e];
+  }
+  return v;
+}
+
+__device__ __forceinline__ void store4(float* p, int f0, int lim, bool vec, f32x4 v) {
+  if (vec) {
+    if (f0 < lim) *reinterpret_cast<f32x4*>(p + f0) = v;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (f0 + e < lim) p[f0 + e] = v[e];
+  }
+}
+
+template <int KT, bool VEC>
+__global__ __launch_bounds__(256) void mha_dq_kernel(MhaBwdArgs a, int QT, int64_t n_units) {
+  const int lane = threadIdx.x & 63;
+  const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit >= n_units) return;
+  const int qt = (int)(unit % QT);
+  const int64_t uh = unit / QT;
+  const int hd = (int)(uh % a.n_heads);
+  const int64_t seq = uh / a.n_heads;
+  const int c = lane & 15, g = lane >> 4;
+  const int S = a.S, dk = a.d_k;
+  const int64_t row0 = seq * S;
+  const int hoff = hd * dk;
+  const int query = qt * 16 + c;
+  const bool qvalid = query < S;
+  const int64_t qrow_i = row0 + (qvalid ? query : 0);
+
+  f32x4 s[KT], dp[KT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dp[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float* qrow = a.q + qrow_i * a.ld + hoff;
+  const float* dorow = a.d_o + qrow_i * a.lddo + hoff;
+  const int nfb = (dk + 15) >> 4;
+  for (int fb = 0; fb < nfb; ++fb) {
+    const int f0 = fb * 16 + 4 * g;
+    f32x4 qf = {0.f, 0.f, 0.f, 0.f}, df = {0.f, 0.f, 0.f, 0.f};
+    if (qvalid) {
+      qf = load4(qrow, f0, dk, VEC);
+      df = load4(dorow, f0, dk, VEC);
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      const int key = kt * 16 + c;
+      f32x4 kf = {0.f, 0.f, 0.f, 0.f}, vf = {0.f, 0.f, 0.f, 0.f};
+      if (key < S) {
+        kf = load4(a.k + (row0 + key) * a.ld + hoff, f0, dk, VEC);
+        vf = load4(a.v + (row0 + key) * a.ld + hoff, f0, dk, VEC);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qf[e], s[kt], 0, 0, 0);
+        dp[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[e], df[e], dp[kt], 0, 0, 0);
+      }
+    }
+  }
+  float mq = 1.f, mx = 0.f, sum = 1.f, delta = 0.f;
+  if (qvalid) {
+    if (a.mask) {
+      const int64_t mrow = a.mask_gather_ids ? (int64_t)a.mask_gather_ids[seq] * S : row0;
+      mq = a.mask[mrow + query];
+    }
+    const int64_t si = (seq * a.n_heads + hd) * (int64_t)S + query;
+    mx = a.stats[2 * si];
+    sum = a.stats[2 * si + 1];
+    delta = a.delta[si];
+  }
+  const float sq = sqrtf((float)dk);
+  const float keep = 1.f - a.dropout_p;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kt * 16 + 4 * g + r;
+      float sv = s[kt][r];
+      if (a.scaled) sv = sv / sq;
+      float ds = 0.f;
+      if (mq != 0.f && key < S && qvalid) {
+        const float p = expf(sv - mx) / sum;
+        float dpv = dp[kt][r];
+        if (a.dropout_p > 0.f) {
+          const uint64_t idx = ((uint64_t)(seq * a.n_heads + hd) * S + (uint64_t)query) * S + (uint64_t)key;
+          dpv = (uniform01(a.seed, idx) < keep) ? dpv / keep : 0.f;
+        }
+        ds = p * (dpv - delta);
+        if (a.scaled) ds = ds / sq;
+      }
+      s[kt][r] = ds;
+    }
+  }
+  // dQ^T[f][query] = sum_key K^T[f][key] dS^T[key][query]
+  const int nft = (dk + 15) >> 4;
+  for (int ft = 0; ft < nft; ++ft) {
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    const int fa = ft * 16 + c;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      float kk[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + 4 * g + r;
+        kk[r] = (key < S && fa < dk) ? a.k[(row0 + key) * a.ld + hoff + fa] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[r], s[kt][r], o, 0, 0, 0);
+    }
+    if (qvalid) store4(a.dq + (row0 + query) * a.ldd + hoff, ft * 16 + 4 * g, dk, VEC, o);
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void mha_dkdv_kernel(MhaBwdArgs a, int KTn, int64_t n_units) {
+  const int lane = threadIdx.x & 63;
+  const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit >= n_units) return;
+  const int kt0 = (int)(unit % KTn);
+  const int64_t uh = unit / KTn;
+  const int hd = (int)(uh % a.n_heads);
+  const int64_t seq = uh / a.n_heads;
+  const int c = lane & 15, g = lane >> 4;
+  const int S = a.S, dk = a.d_k;
+  const int64_t row0 = seq * S;
+  const int hoff = hd * dk;
+  const int key = kt0 * 16 + c;
+  const bool kvalid = key < S;
+  const int64_t krow_i = row0 + (kvalid ? key : 0);
+  const float* krow = a.k + krow_i * a.ld + hoff;
+  const float* vrow = a.v + krow_i * a.ld + hoff;
+  const int nfb = (dk + 15) >> 4;
+  const float sq = sqrtf((float)dk);
+  const float keep = 1.f - a.dropout_p;
+  const int64_t mrow = a.mask ? (a.mask_gather_ids ? (int64_t)a.mask_gather_ids[seq] * S : row0) : 0;
+  const int64_t sbase = (seq * a.n_heads + hd) * (int64_t)S;
+
+  f32x4 dkT[MAX_FT], dvT[MAX_FT];
+#pragma unroll
+  for (int t = 0; t < MAX_FT; ++t) {
+    dkT[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dvT[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int QT = (S + 15) >> 4;
+  for (int qt = 0; qt < QT; ++qt) {
+    const int qa = qt * 16 + c;  // the query this lane feeds as an A-operand row
+    const bool qa_valid = qa < S;
+    const int64_t qa_row = row0 + (qa_valid ? qa : 0);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+    for (int fb = 0; fb < nfb; ++fb) {
+      const int f0 = fb * 16 + 4 * g;
+      f32x4 qf = {0.f, 0.f, 0.f, 0.f}, df = {0.f, 0.f, 0.f, 0.f}, kf = {0.f, 0.f, 0.f, 0.f}, vf = {0.f, 0.f, 0.f, 0.f};
+      if (qa_valid) {
+        qf = load4(a.q + qa_row * a.ld + hoff, f0, dk, VEC);
+        df = load4(a.d_o + qa_row * a.lddo + hoff, f0, dk, VEC);
+      }
+      if (kvalid) {
+        kf = load4(krow, f0, dk, VEC);
+        vf = load4(vrow, f0, dk, VEC);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[e], kf[e], s, 0, 0, 0);    // S[query 4g+r][key c]
+        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(df[e], vf[e], dp, 0, 0, 0);  // dPd[query 4g+r][key c]
+      }
+    }
+    f32x4 pd, ds;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int query = qt * 16 + 4 * g + r;
+      float pdv = 0.f, dsv = 0.f;
+      if (query < S && kvalid) {
+        const float mq = a.mask ? a.mask[mrow + query] : 1.f;
+        const float mx = a.stats[2 * (sbase + query)];
+        const float sum = a.stats[2 * (sbase + query) + 1];
+        const float delta = a.delta[sbase + query];
+        float sv = s[r];
+        if (a.scaled) sv = sv / sq;
+        if (mq == 0.f) sv = -1e9f;
+        const float p = expf(sv - mx) / sum;
+        float dpv = dp[r];
+        pdv = p;
+        if (a.dropout_p > 0.f) {
+          const uint64_t idx = ((uint64_t)(seq * a.n_heads + hd) * S + (uint64_t)query) * S + (uint64_t)key;
+          const bool kp = uniform01(a.seed, idx) < keep;
+          pdv = kp ? p / keep : 0.f;
+          dpv = kp ? dpv / keep : 0.f;
+        }
+        if (mq != 0.f) {
+          dsv = p * (dpv - delta);
+          if (a.scaled) dsv = dsv / sq;
+        }
+      }
+      pd[r] = pdv;
+      ds[r] = dsv;
+    }
+    // dV^T[dv][key] += dO^T[dv][query] Pd[query][key];  dK^T[f][key] += Q^T[f][query] dS[query][key]
+#pragma unroll
+    for (int t = 0; t < MAX_FT; ++t) {
+      if (t < nfb) {
+        const int fa = t * 16 + c;
+        float dd[4], qq[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int query = qt * 16 + 4 * g + r;
+          const bool ok = query < S && fa < dk;
+          dd[r] = ok ? a.d_o[(row0 + query) * a.lddo + hoff + fa] : 0.f;
+          qq[r] = ok ? a.q[(row0 + query) * a.ld + hoff + fa] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dvT[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(dd[r], pd[r], dvT[t], 0, 0, 0);
+          dkT[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qq[r], ds[r], dkT[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (kvalid) {
+    float* dkrow = a.dk + (row0 + key) * a.ldd + hoff;
+    float* dvrow = a.dv + (row0 + key) * a.ldd + hoff;
+#pragma unroll
+    for (int t = 0; t < MAX_FT; ++t) {
+      if (t < nfb) {
+        store4(dkrow, t * 16 + 4 * g, dk, VEC, dkT[t]);
+        store4(dvrow, t * 16 + 4 * g, dk, VEC, dvT[t]);
+      }
+    }
+  }
+}
+
+template <int KT>
+static hipError_t launch_dq(const MhaBwdArgs& a, bool vec, hipStream_t stream) {
+  const int QT = (a.S + 15) / 16;
+  const int64_t n_units = a.n_seq * a.n_heads * QT;
+  const dim3 grid((unsigned)((n_units + 3) / 4));
+  if (vec) hipLaunchKernelGGL((mha_dq_kernel<KT, true>), grid, dim3(256), 0, stream, a, QT, n_units);
+  else hipLaunchKernelGGL((mha_dq_kernel<KT, false>), grid, dim3(256), 0, stream, a, QT, n_units);
+  return hipGetLastError();
+}
+
+hipError_t launch_mha_bwd(const MhaBwdArgs& a, hipStream_t stream) {
+  if (a.n_seq <= 0 || a.S <= 0) return hipSuccess;
+  if (a.S > 128 || a.d_k > 16 * MAX_FT) return hipErrorInvalidValue;
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool vec = (a.d_k % 4 == 0) && (a.ld % 4 == 0) && (a.lddo % 4 == 0) && (a.ldd % 4 == 0) && al16(a.q) && al16(a.k) &&
+                   al16(a.v) && al16(a.d_o) && al16(a.dq) && al16(a.dk) && al16(a.dv);
+  const int64_t n = a.n_seq * a.n_heads * a.S;
+  hipLaunchKernelGGL(mha_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, n);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const int KT = (a.S + 15) / 16;
+  switch (KT) {
+    case 1: e = launch_dq<1>(a, vec, stream); break;
+    case 2: e = launch_dq<2>(a, vec, stream); break;
+    case 3: e = launch_dq<3>(a, vec, stream); break;
+    case 4: e = launch_dq<4>(a, vec, stream); break;
+    case 5: e = launch_dq<5>(a, vec, stream); break;
+    case 6: e = launch_dq<6>(a, vec, stream); break;
+    case 7: e = launch_dq<7>(a, vec, stream); break;
+    default: e = launch_dq<8>(a, vec, stream); break;
+  }
+  if (e != hipSuccess) return e;
+  const int64_t n_units = a.n_seq * a.n_heads * KT;
+  const dim3 grid((unsigned)((n_units + 3) / 4));
+  if (vec) hipLaunchKernelGGL((mha_dkdv_kernel<true>), grid, dim3(256), 0, stream, a, KT, n_units);
+  else hipLaunchKernelGGL((mha_dkdv_kernel<false>), grid, dim3(256), 0, stream, a, KT, n_units);
+  return hipGetLastError();
+}
+
+}  // namespace xnrs

@@ -22,17 +22,6 @@
 
 namespace xnrs {
 
-// counter-based RNG for attention dropout (training mode only): splitmix64 finaliser on
-// (seed, element index) -> uniform [0,1).  Parity with torch's CPU Philox stream is impossible
-// (SURVEY.md section 7 "hard parts"); only the distribution matters.
-__device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (float)(z >> 40) * (1.0f / 16777216.0f);
-}
-
 template <int KT, bool VEC>
 __global__ __launch_bounds__(256) void mha_core_kernel(MhaCoreArgs a, int QT, int64_t n_units) {
   const int lane = threadIdx.x & 63;
@@ -123,6 +112,11 @@ __global__ __launch_bounds__(256) void mha_core_kernel(MhaCoreArgs a, int QT, in
   }
   sum += __shfl_xor(sum, 16);
   sum += __shfl_xor(sum, 32);
+  if (a.stats && qvalid && g == 0) {
+    float* st = a.stats + ((seq * a.n_heads + hd) * (int64_t)S + query) * 2;
+    st[0] = mx;
+    st[1] = sum;
+  }
   const float keep = 1.f - a.dropout_p;
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {

@@ -1,0 +1,178 @@
+// Backward kernels of the pooling / scoring stages and the column reductions that produce bias and
+// fc2 gradients.  fp32, deterministic (no float atomics: two-stage ordered reductions).
+//   additive_pool_bwd : autograd of layers.AdditiveAttention.forward after fc1+tanh (layers.py:60-65)
+//   mean_pool_bwd     : autograd of layers.MaskedMean.forward (layers.py:35-36)
+//   colsum            : out[n] = sum_m w[m] * X[m][n]  (bias grads: w == NULL; fc2.weight grad: X = tanh(fc1 x), w = de)
+//   dot_scoring_bwd   : autograd of DotScoring.forward, normalize=False (scoring.py:23)
+#include "kernels.h"
+
+namespace xnrs {
+
+__device__ __forceinline__ float wave_sum_b(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+constexpr int POOLB_MAX_N = 512;
+
+// forward: s_i = exp(e_i) m_i, Z = sum s + 1e-8, a_i = s_i / Z, p = sum a_i x_i  with  e_i = w2.t_i + b2
+// backward (dp given):  da_i = dp.x_i ;  de_i = a_i (da_i - sum_j a_j da_j)
+//   dx_i  = a_i dp                        (the fc1 path adds dpre.W1 on top, as a GEMM)
+//   dpre_i = de_i * w2 * (1 - t_i^2)      (gradient at the fc1 pre-activation)
+__global__ __launch_bounds__(256) void additive_pool_bwd_kernel(AdditivePoolBwdArgs a) {
+  __shared__ float s_a[POOLB_MAX_N];
+  __shared__ float s_da[POOLB_MAX_N];
+  __shared__ float s_red[4];
+  const int64_t seq = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = a.N, A = a.A, D = a.D;
+  const int64_t srcx = a.x_gather_ids ? (int64_t)a.x_gather_ids[seq] : seq;
+  const float* x = a.x + srcx * N * a.ldx;
+  const float* dp = a.dp + seq * D;
+  for (int i = wave; i < N; i += 4) {
+    const float* xi = x + (int64_t)i * a.ldx;
+    float acc = 0.f;
+    for (int d = lane; d < D; d += 64) acc = fmaf(dp[d], xi[d], acc);
+    acc = wave_sum_b(acc);
+    if (lane == 0) {
+      s_da[i] = acc;
+      s_a[i] = a.a[seq * N + i];
+    }
+  }
+  __syncthreads();
+  float part = 0.f;
+  for (int i = tid; i < N; i += 256) part = fmaf(s_a[i], s_da[i], part);
+  part = wave_sum_b(part);
+  if (lane == 0) s_red[wave] = part;
+  __syncthreads();
+  const float cdot = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+  __syncthreads();
+  for (int i = tid; i < N; i += 256) {
+    const float de = s_a[i] * (s_da[i] - cdot);
+    s_da[i] = de;
+    a.de[seq * N + i] = de;
+  }
+  __syncthreads();
+  if (a.dx) {
+    for (int i = 0; i < N; ++i) {
+      const float ai = s_a[i];
+      float* dxi = a.dx + (seq * N + i) * a.lddx;
+      for (int d = tid; d < D; d += 256) dxi[d] = ai * dp[d];
+    }
+  }
+  for (int i = 0; i < N; ++i) {
+    const float de = s_da[i];
+    const float* ti = a.t + (seq * N + i) * (int64_t)A;
+    float* dpre = a.dpre + (seq * N + i) * (int64_t)A;
+    for (int k = tid; k < A; k += 256) {
+      const float tv = ti[k];
+      dpre[k] = de * a.w2[k] * (1.f - tv * tv);
+    }
+  }
+}
+
+hipError_t launch_additive_pool_bwd(const AdditivePoolBwdArgs& a, hipStream_t stream) {
+  if (a.n_seq <= 0) return hipSuccess;
+  if (a.N > POOLB_MAX_N || a.N <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(additive_pool_bwd_kernel, dim3((unsigned)a.n_seq), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+// y = sum_i x_i m_i / (sum m + 1e-8)  ->  dx_i = dy * m_i / (sum m + 1e-8)
+__global__ __launch_bounds__(256) void mean_pool_bwd_kernel(const float* dy, const float* mask, const int32_t* mask_ids,
+                                                             float* dx, int64_t lddx, int N, int D) {
+  __shared__ float s_red[4];
+  const int64_t seq = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t src = mask_ids ? (int64_t)mask_ids[seq] : seq;
+  float part = 0.f;
+  for (int i = tid; i < N; i += 256) part += mask[src * N + i];
+  part = wave_sum_b(part);
+  if (lane == 0) s_red[wave] = part;
+  __syncthreads();
+  const float denom = (s_red[0] + s_red[1] + s_red[2] + s_red[3]) + 1e-8f;
+  for (int i = 0; i < N; ++i) {
+    const float w = mask[src * N + i] / denom;
+    for (int d = tid; d < D; d += 256) dx[(seq * N + i) * lddx + d] = dy[seq * D + d] * w;
+  }
+}
+
+hipError_t launch_mean_pool_bwd(const float* dy, const float* mask, const int32_t* mask_ids, float* dx, int64_t lddx,
+                                int64_t n_seq, int32_t N, int32_t D, hipStream_t stream) {
+  if (n_seq <= 0) return hipSuccess;
+  hipLaunchKernelGGL(mean_pool_bwd_kernel, dim3((unsigned)n_seq), dim3(256), 0, stream, dy, mask, mask_ids, dx, lddx, N, D);
+  return hipGetLastError();
+}
+
+// ---- column sums: stage 1 writes partial[split][n], stage 2 sums the splits in order
+constexpr int COLSUM_SPLITS = 64;
+
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* X, int64_t ldx, const float* w, int64_t M, int N,
+                                                              float* partial) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int sp = blockIdx.y;
+  const int64_t per = (M + gridDim.y - 1) / gridDim.y;
+  const int64_t r0 = sp * per;
+  const int64_t r1 = (r0 + per < M) ? r0 + per : M;
+  if (n >= N) return;
+  float acc = 0.f;
+  if (w) {
+    for (int64_t r = r0; r < r1; ++r) acc = fmaf(w[r], X[r * ldx + n], acc);
+  } else {
+    for (int64_t r = r0; r < r1; ++r) acc += X[r * ldx + n];
+  }
+  partial[(int64_t)sp * N + n] = acc;
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, int nsplit, int N, float* out) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float acc = 0.f;
+  for (int s = 0; s < nsplit; ++s) acc += partial[(int64_t)s * N + n];
+  out[n] = acc;
+}
+
+size_t colsum_workspace_bytes(int N) { return (size_t)COLSUM_SPLITS * (size_t)N * sizeof(float); }
+
+hipError_t launch_colsum(const float* X, int64_t ldx, const float* w, int64_t M, int N, float* out, float* partial,
+                         hipStream_t stream) {
+  if (N <= 0) return hipSuccess;
+  int nsplit = (int)((M + 255) / 256);
+  if (nsplit > COLSUM_SPLITS) nsplit = COLSUM_SPLITS;
+  if (nsplit < 1) nsplit = 1;
+  const dim3 g1((unsigned)((N + 255) / 256), (unsigned)nsplit);
+  hipLaunchKernelGGL(colsum_partial_kernel, g1, dim3(256), 0, stream, X, ldx, w, M, N, partial);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, partial, nsplit, N, out);
+  return hipGetLastError();
+}
+
+// r[b,c] = <c[b,c,:], u[b,:]>  ->  du[b,e] = sum_c dr[b,c] c[b,c,e] ;  dc[b,c,e] = dr[b,c] u[b,e]
+__global__ __launch_bounds__(256) void dot_scoring_bwd_kernel(const float* u, const float* c, const float* dr, float* du,
+                                                               float* dc, int64_t B, int C, int E) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * E) return;
+  const int64_t b = i / E;
+  const int e = (int)(i - b * E);
+  const float uv = u[i];
+  float acc = 0.f;
+  for (int k = 0; k < C; ++k) {
+    const float g = dr[b * C + k];
+    acc = fmaf(g, c[(b * C + k) * E + e], acc);
+    if (dc) dc[(b * C + k) * E + e] = g * uv;
+  }
+  if (du) du[i] = acc;
+}
+
+hipError_t launch_dot_scoring_bwd(const float* u, const float* c, const float* dr, float* du, float* dc, int64_t B, int32_t C,
+                                  int32_t E, hipStream_t stream) {
+  const int64_t n = B * E;
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(dot_scoring_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, u, c, dr, du, dc, B, C,
+                     E);
+  return hipGetLastError();
+}
+
+}  // namespace xnrs
