@@ -125,6 +125,61 @@ int32_t xnrs_user_encoder_fwd(const float *x, const float *m, int64_t B, int32_t
 int32_t xnrs_dot_scoring_fwd(const float *u, const float *c, float *r, int64_t B, int32_t C, int32_t E,
                              int32_t normalize, void *stream);
 
+/* ---- training: forward that keeps its activations + backward --------------------------------
+ * Autograd of the sequence-encoder pipeline (TextEncoder news_encoding.py:34-60, UserEncoder
+ * user_encoding.py:50-81, and their parts when pool_kind == XNRS_POOL_NONE / att == NULL), as needed by
+ * the grad step (training.py:402-431: loss.backward()) and by integrated gradients (explain.py:160-166,
+ * which needs d score / d x).
+ *   fwd_train : same arithmetic as xnrs_text_encoder_fwd / xnrs_user_encoder_fwd, one pass (no chunking),
+ *               intermediates are kept in the caller's `saved` buffer (xnrs_seq_encoder_saved_bytes).
+ *   bwd       : dy:(n_seq,E') [pool_kind == XNRS_POOL_NONE: (n_seq,L,D)] -> parameter gradients (each
+ *               pointer of the *_grads structs may be NULL = not wanted; values are WRITTEN, not
+ *               accumulated) and, if dx != NULL, the input gradient dx:(n_seq,L,D) (not available with
+ *               ids: a gathered table gets no gradient).  Deterministic: no float atomics. */
+#define XNRS_POOL_NONE (-1) /* no pooler: y = att(x), the MultiHeadAttention module alone */
+typedef struct {
+  float *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo;
+} xnrs_mha_grads;
+typedef struct {
+  float *w1, *b1, *w2, *b2;
+} xnrs_additive_grads;
+typedef struct {
+  float *w0, *b0, *w2, *b2;
+} xnrs_head_grads;
+
+size_t xnrs_seq_encoder_saved_bytes(int64_t n_seq, int32_t L, int32_t D, int32_t A, int32_t E, int32_t n_heads,
+                                    int32_t pool_kind, int32_t has_head);
+int32_t xnrs_seq_encoder_fwd_train(const float *x, const float *m, const int32_t *ids, int64_t n_seq, int32_t L,
+                                   int32_t D, const xnrs_mha_params *att, int32_t pool_kind,
+                                   const xnrs_additive_params *pool, const xnrs_head_params *head, float *y,
+                                   float *a_out, float *hm, void *saved, size_t saved_bytes, void *stream);
+size_t xnrs_seq_encoder_bwd_workspace_bytes(int64_t n_seq, int32_t L, int32_t D, int32_t A, int32_t E,
+                                            int32_t n_heads, int32_t pool_kind, int32_t has_head);
+int32_t xnrs_seq_encoder_bwd(const float *x, const float *m, const int32_t *ids, int64_t n_seq, int32_t L, int32_t D,
+                             const xnrs_mha_params *att, int32_t pool_kind, const xnrs_additive_params *pool,
+                             const xnrs_head_params *head, const void *saved, size_t saved_bytes, const float *dy,
+                             float *dx, const xnrs_mha_grads *g_att, const xnrs_additive_grads *g_pool,
+                             const xnrs_head_grads *g_head, void *ws, size_t ws_bytes, void *stream);
+
+/* autograd of nn.Linear (xnrs_linear_fwd): dx = dy.W (nullable), dw = dy^T.x, db = colsum(dy) (nullable).
+ * gather_ids as in the forward (then dx must be NULL). */
+size_t xnrs_linear_bwd_workspace_bytes(int64_t M, int32_t N, int32_t K);
+int32_t xnrs_linear_bwd(const float *x, const int32_t *gather_ids, int32_t gather_S, const float *w, const float *dy,
+                        float *dx, float *dw, float *db, int64_t M, int32_t N, int32_t K, void *ws, size_t ws_bytes,
+                        void *stream);
+
+/* autograd of fc(embedder(idx)) (naml.py:82-86; forward = xnrs_linear_fwd with gather_S = 1):
+ * dw:(N,K) = dy^T . table[ids], db:(N) = colsum(dy), d_table:(n_rows,K) = scatter-add of dy.W by ids
+ * (deterministic).  ws: xnrs_embedding_linear_bwd_workspace_bytes. */
+size_t xnrs_embedding_linear_bwd_workspace_bytes(int64_t M, int32_t N, int32_t K);
+int32_t xnrs_embedding_linear_bwd(const float *table, const int32_t *ids, const float *w, const float *dy, float *d_table,
+                                  float *dw, float *db, int64_t M, int32_t N, int32_t K, int32_t n_rows, void *ws,
+                                  size_t ws_bytes, void *stream);
+
+/* autograd of DotScoring.forward with normalize == 0 (scoring.py:23): du:(B,E), dc:(B,C,E), either nullable */
+int32_t xnrs_dot_scoring_bwd(const float *u, const float *c, const float *dr, float *du, float *dc, int64_t B,
+                             int32_t C, int32_t E, void *stream);
+
 /* ---- measurement aid (no reference counterpart) ----------------------------------------------
  * When enabled, the sequence-encoder pipeline brackets each kernel launch of the selected stages
  * with hipEvents on the caller's stream (the only process-global state in the library; off by

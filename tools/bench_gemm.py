@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""A/B micro-benchmark of the fp32 MFMA GEMM variants (interleaved rounds in ONE process).
+
+    python tools/bench_gemm.py            # on the GPU box
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from xnrs_amd import hip, ops  # noqa: E402
+
+dev = torch.device("cuda", 0)
+shapes = [(65500, 2304, 768), (65500, 768, 768), (30720, 960, 320)]
+names = sys.argv[1].split(",") if len(sys.argv) > 1 else ["p1k32g", "p2k32b", "p4k32b", "p3k32b", "p3k32g", "p3k16b", "p1k16b"]
+variants = {v: {"XNRS_GEMM_PIPE": v[1], "XNRS_GEMM_BK": v[3:5], "XNRS_GEMM_BUF": "1" if v[5] == "b" else "0"} for v in names}
+torch.manual_seed(0)
+for (M, N, K) in shapes:
+    x = torch.randn(M, K, device=dev)
+    w = torch.randn(N, K, device=dev) / K ** 0.5
+    b = torch.randn(N, device=dev)
+    ref = None
+    res = {v: [] for v in variants}
+    for rnd in range(5):
+        for v, env in variants.items():
+            os.environ.update(env)
+            y = ops.linear(x, w, b)  # warm
+            if rnd == 0:
+                if ref is None:
+                    ref = y.clone()
+                else:
+                    assert torch.equal(ref, y), f"variant {v} differs"
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                ops.linear(x, w, b)
+            e1.record()
+            torch.cuda.synchronize()
+            res[v].append(e0.elapsed_time(e1) / 10)
+    fl = 2.0 * M * N * K
+    print(f"M={M} N={N} K={K}: " + "  ".join(
+        f"{v}: {fl/sorted(t)[len(t)//2]/1e9:.1f} TF" for v, t in res.items()))

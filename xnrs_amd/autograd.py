@@ -1,9 +1,305 @@
-"""Autograd bridge for the HIP hot path (training / integrated gradients).  Placeholder until the
-backward kernels land: requesting gradients fails loudly instead of silently using torch ops."""
+"""Autograd bridge: torch.autograd.Function wrappers around the training entry points of
+libxnrs_hip.so (forward that keeps its activations + hand-written backward kernels).
+
+Needed by the grad step (xnrs/training.py:402-431: loss.backward(); Adam) and by integrated
+gradients (xnrs/explain.py:160-166: d score / d x).  Everything differentiable on the hot path goes
+through HIP kernels; torch only routes gradients between the Functions.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+
+from . import hip
+
+_ATT_NAMES = ("q_linear.weight", "q_linear.bias", "k_linear.weight", "k_linear.bias",
+              "v_linear.weight", "v_linear.bias", "out.weight", "out.bias")
 
 
-def _nyi(*a, **k):
-    raise NotImplementedError("xnrs_amd: backward kernels are not built yet; run under torch.no_grad()")
+def _att_tensors(att) -> List[torch.Tensor]:
+    return [att.q_linear.weight, att.q_linear.bias, att.k_linear.weight, att.k_linear.bias,
+            att.v_linear.weight, att.v_linear.bias, att.out.weight, att.out.bias]
 
 
-mha = additive = text_encoder = user_encoder = embedding_linear = _nyi
+def _pool_tensors(pool) -> List[torch.Tensor]:
+    return [pool.fc1.weight, pool.fc1.bias, pool.fc2.weight, pool.fc2.bias]
+
+
+def _head_tensors(head) -> List[Optional[torch.Tensor]]:
+    return [head[0].weight, head[0].bias, head[2].weight, head[2].bias]
+
+
+class _Cfg:
+    """Static (non-tensor) description of one sequence-encoder call."""
+
+    def __init__(self, n_seq, L, D, n_heads, scaled, pool_kind, A, has_head, E, head_bias, dropout_p, seed, want_a):
+        self.n_seq, self.L, self.D = n_seq, L, D
+        self.n_heads, self.scaled = n_heads, scaled
+        self.pool_kind, self.A = pool_kind, A
+        self.has_head, self.E, self.head_bias = has_head, E, head_bias
+        self.dropout_p, self.seed = dropout_p, seed
+        self.want_a = want_a
+
+
+def _param_structs(cfg: _Cfg, params: List[Optional[torch.Tensor]]):
+    """Split the flat parameter list (att 8 | pool 4 | head 4) back into the C structs."""
+    i = 0
+    ap = pp = hp = None
+    keep = []
+    if cfg.n_heads > 0:
+        ts = [hip.dev_f32(t, "mha weight") for t in params[i:i + 8]]
+        ap = hip.MhaParams(*[t.data_ptr() for t in ts], cfg.n_heads, 1 if cfg.scaled else 0, float(cfg.dropout_p),
+                           int(cfg.seed))
+        keep += ts
+        i += 8
+    if cfg.pool_kind == hip.POOL_ADDITIVE:
+        ts = [hip.dev_f32(t, "additive weight") for t in params[i:i + 4]]
+        pp = hip.AdditiveParams(*[t.data_ptr() for t in ts], cfg.A)
+        keep += ts
+        i += 4
+    if cfg.has_head:
+        ts = [None if t is None else hip.dev_f32(t, "head weight") for t in params[i:i + 4]]
+        hp = hip.HeadParams(*[None if t is None else t.data_ptr() for t in ts], cfg.E)
+        keep += ts
+        i += 4
+    return ap, pp, hp, keep
+
+
+def _ref(s):
+    return None if s is None else C.byref(s)
+
+
+class _SeqEncode(torch.autograd.Function):
+    """y = head(pool(att(x)))  (any stage optional) with saved activations for the HIP backward."""
+
+    @staticmethod
+    def forward(ctx, cfg: _Cfg, x, m, ids, *params):
+        x = hip.dev_f32(x, "encoder input")
+        dev = x.device
+        n, L, D = cfg.n_seq, cfg.L, cfg.D
+        ap, pp, hp, keep = _param_structs(cfg, list(params))
+        pooled = cfg.pool_kind != hip.POOL_NONE
+        Eo = cfg.E if cfg.has_head else D
+        y = torch.empty((n, Eo) if pooled else (n, L, D), dtype=torch.float32, device=dev)
+        a = torch.empty((n, L), dtype=torch.float32, device=dev) if (cfg.want_a and cfg.pool_kind == hip.POOL_ADDITIVE) else None
+        hm = torch.empty((n,), dtype=torch.float32, device=dev) if (pooled and m is not None) else None
+        l = hip.lib()
+        nsaved = l.xnrs_seq_encoder_saved_bytes(n, L, D, cfg.A, Eo, cfg.n_heads, cfg.pool_kind, int(cfg.has_head))
+        saved = torch.empty(max(nsaved, 1), dtype=torch.uint8, device=dev)
+        hip.check(l.xnrs_seq_encoder_fwd_train(hip.ptr(x), hip.ptr(m), hip.ptr(ids), n, L, D, _ref(ap), cfg.pool_kind,
+                                               _ref(pp), _ref(hp), hip.ptr(y), hip.ptr(a), hip.ptr(hm), hip.ptr(saved),
+                                               nsaved, hip.stream_ptr(dev)), "xnrs_seq_encoder_fwd_train")
+        ctx.cfg = cfg
+        ctx.nsaved = nsaved
+        ctx.n_params = len(params)
+        ctx.save_for_backward(x, m, ids, saved, *[p for p in params if p is not None])
+        ctx.param_none = [p is None for p in params]
+        outs = [y, a if a is not None else y.new_empty(0), hm if hm is not None else y.new_empty(0)]
+        ctx.mark_non_differentiable(outs[1], outs[2])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, dy, _da, _dhm):
+        cfg = ctx.cfg
+        x, m, ids, saved, *ptensors = ctx.saved_tensors
+        it = iter(ptensors)
+        params = [None if isnone else next(it) for isnone in ctx.param_none]
+        dev = x.device
+        n, L, D = cfg.n_seq, cfg.L, cfg.D
+        Eo = cfg.E if cfg.has_head else D
+        ap, pp, hp, keep = _param_structs(cfg, params)
+        dy = hip.dev_f32(dy, "grad output")
+        need = ctx.needs_input_grad  # (cfg, x, m, ids, *params)
+        want_dx = need[1]
+        if want_dx and ids is not None:
+            raise hip.XnrsHipError("no input gradient through an id-gathered news table")
+        dx = torch.empty((n, L, D), dtype=torch.float32, device=dev) if want_dx else None
+        grads: List[Optional[torch.Tensor]] = []
+        for j, p in enumerate(params):
+            grads.append(torch.empty_like(p, dtype=torch.float32) if (p is not None and need[4 + j]) else None)
+        i = 0
+        ga = gp = gh = None
+        if cfg.n_heads > 0:
+            ga = hip.MhaGrads(*[None if g is None else g.data_ptr() for g in grads[i:i + 8]])
+            i += 8
+        if cfg.pool_kind == hip.POOL_ADDITIVE:
+            gp = hip.AdditiveGrads(*[None if g is None else g.data_ptr() for g in grads[i:i + 4]])
+            i += 4
+        if cfg.has_head:
+            gh = hip.HeadGrads(*[None if g is None else g.data_ptr() for g in grads[i:i + 4]])
+            i += 4
+        l = hip.lib()
+        nws = l.xnrs_seq_encoder_bwd_workspace_bytes(n, L, D, cfg.A, Eo, cfg.n_heads, cfg.pool_kind, int(cfg.has_head))
+        ws = hip.workspace(dev, nws)
+        hip.check(l.xnrs_seq_encoder_bwd(hip.ptr(x), hip.ptr(m), hip.ptr(ids), n, L, D, _ref(ap), cfg.pool_kind, _ref(pp),
+                                         _ref(hp), hip.ptr(saved), ctx.nsaved, hip.ptr(dy), hip.ptr(dx), _ref(ga), _ref(gp),
+                                         _ref(gh), hip.ptr(ws), nws, hip.stream_ptr(dev)), "xnrs_seq_encoder_bwd")
+        return (None, dx, None, None, *grads)
+
+
+def _run(x, m, ids, att, pooler, head, pool_kind, dropout_p, seed, want_a):
+    from . import ops
+    x = hip.dev_f32(x, "encoder input")
+    n_tab, L, D = x.shape
+    m2 = ops._mask2d(m, n_tab, L, "encoder mask")
+    if ids is not None:
+        ids = ids.to(torch.int32).contiguous()
+        n = ids.numel()
+    else:
+        n = n_tab
+    params: List[Optional[torch.Tensor]] = []
+    n_heads, scaled, A, E, has_head, head_bias = 0, True, 0, D, False, False
+    if att is not None:
+        params += _att_tensors(att)
+        n_heads, scaled = att.h, att.scaled
+    if pool_kind == hip.POOL_ADDITIVE:
+        params += _pool_tensors(pooler)
+        A = pooler.fc1.out_features
+    if head is not None:
+        params += _head_tensors(head)
+        has_head, E = True, head[0].out_features
+    cfg = _Cfg(n, L, D, n_heads, scaled, pool_kind, A, has_head, E, head_bias, dropout_p, seed, want_a)
+    y, a, hm = _SeqEncode.apply(cfg, x, m2, ids, *params)
+    return y, (a if a.numel() else None), (hm if hm.numel() else None)
+
+
+def _pool_kind(pooler):
+    from .models.components import layers
+    if isinstance(pooler, layers.AdditiveAttention):
+        return hip.POOL_ADDITIVE
+    if isinstance(pooler, layers.MaskedMean):
+        return hip.POOL_MEAN
+    raise hip.XnrsHipError(f"pooler {type(pooler).__name__} has no HIP implementation")
+
+
+# ------------------------------------------------------------------------- entry points used by ops.py
+def mha(x, m, att, dropout_p, seed):
+    y, _, _ = _run(x, m, None, att, None, None, hip.POOL_NONE, dropout_p, seed, False)
+    return y
+
+
+def additive(x, m, pool, return_weights):
+    y, a, _ = _run(x, m, None, None, pool, None, hip.POOL_ADDITIVE, 0.0, 0, return_weights)
+    y = y.unsqueeze(1)
+    return (y, a.unsqueeze(-1)) if return_weights else y
+
+
+def masked_mean(x, m):
+    from .models.components import layers
+    y, _, _ = _run(x, m, None, None, layers.MaskedMean(), None, hip.POOL_MEAN, 0.0, 0, False)
+    return y.unsqueeze(1)
+
+
+def text_encoder(x, m, enc, ids, dropout_p, seed):
+    head = getattr(enc, "head", None)
+    y, _, hm = _run(x, m, ids, enc.att, enc.pooler, head, _pool_kind(enc.pooler), dropout_p, seed, False)
+    return y, hm
+
+
+def user_encoder(x, m, enc, return_weights, dropout_p, seed):
+    head = getattr(enc, "head", None)
+    y, a, _ = _run(x, m, None, enc.att, enc.pooler, head, _pool_kind(enc.pooler), dropout_p, seed, return_weights)
+    y = y.unsqueeze(1)
+    return (y, a.unsqueeze(-1)) if return_weights else y
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        from . import ops
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        with torch.no_grad():
+            return ops.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        x = hip.dev_f32(x, "x")
+        w = hip.dev_f32(w, "w")
+        dy = hip.dev_f32(dy, "dy")
+        K, N = w.shape[1], w.shape[0]
+        M = x.numel() // K
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        db = torch.empty(N, dtype=torch.float32, device=x.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        l = hip.lib()
+        nws = l.xnrs_linear_bwd_workspace_bytes(M, N, K)
+        ws = hip.workspace(x.device, nws)
+        hip.check(l.xnrs_linear_bwd(hip.ptr(x), None, 0, hip.ptr(w), hip.ptr(dy), hip.ptr(dx), hip.ptr(dw), hip.ptr(db), M, N,
+                                    K, hip.ptr(ws), nws, hip.stream_ptr(x.device)), "xnrs_linear_bwd")
+        return dx, dw, db
+
+
+def linear(x, w, b):
+    return _Linear.apply(x, w, b)
+
+
+class _EmbeddingLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, table, w, b):
+        tab = hip.dev_f32(table, "embedding table")
+        wd = hip.dev_f32(w, "fc weight")
+        bd = None if b is None else hip.dev_f32(b, "fc bias")
+        idx = ids.to(torch.int32).contiguous()
+        M, K, N = idx.numel(), tab.shape[1], wd.shape[0]
+        y = torch.empty(tuple(ids.shape) + (N,), dtype=torch.float32, device=tab.device)
+        hip.check(hip.lib().xnrs_linear_fwd(hip.ptr(tab), hip.ptr(idx), 1, hip.ptr(wd), hip.ptr(bd), hip.ptr(y), M, N, K,
+                                            hip.ACT_NONE, hip.stream_ptr(tab.device)), "xnrs_linear_fwd(gather)")
+        ctx.save_for_backward(idx, tab, wd)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        idx, tab, w = ctx.saved_tensors
+        dy = hip.dev_f32(dy, "dy")
+        M, K, N = idx.numel(), tab.shape[1], w.shape[0]
+        need = ctx.needs_input_grad
+        d_tab = torch.empty_like(tab) if need[1] else None
+        dw = torch.empty_like(w) if need[2] else None
+        db = torch.empty(N, dtype=torch.float32, device=tab.device) if (ctx.has_bias and need[3]) else None
+        l = hip.lib()
+        nws = l.xnrs_embedding_linear_bwd_workspace_bytes(M, N, K)
+        ws = hip.workspace(tab.device, nws)
+        hip.check(l.xnrs_embedding_linear_bwd(hip.ptr(tab), hip.ptr(idx), hip.ptr(w), hip.ptr(dy), hip.ptr(d_tab), hip.ptr(dw),
+                                              hip.ptr(db), M, N, K, tab.shape[0], hip.ptr(ws), nws,
+                                              hip.stream_ptr(tab.device)), "xnrs_embedding_linear_bwd")
+        return None, d_tab, dw, db
+
+
+def embedding_linear(idx, embedder, fc):
+    if not idx.is_cuda:
+        raise hip.XnrsHipError("category indices must live on the HIP device")
+    return _EmbeddingLinear.apply(idx, embedder.weight, fc.weight, fc.bias)
+
+
+class _DotScoring(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, c):
+        from . import ops
+        u = hip.dev_f32(u, "user vector")
+        c = hip.dev_f32(c, "candidate vectors")
+        ctx.save_for_backward(u, c)
+        with torch.no_grad():
+            return ops.dot_scoring_forward(u, c, False)
+
+    @staticmethod
+    def backward(ctx, dr):
+        u, c = ctx.saved_tensors
+        dr = hip.dev_f32(dr, "dr")
+        B, Cn, E = c.shape
+        du = torch.empty_like(u) if ctx.needs_input_grad[0] else None
+        dc = torch.empty_like(c) if ctx.needs_input_grad[1] else None
+        hip.check(hip.lib().xnrs_dot_scoring_bwd(hip.ptr(u), hip.ptr(c), hip.ptr(dr), hip.ptr(du), hip.ptr(dc), B, Cn, E,
+                                                 hip.stream_ptr(c.device)), "xnrs_dot_scoring_bwd")
+        return du, dc
+
+
+def dot_scoring(u, c, normalize):
+    if normalize:
+        raise NotImplementedError("backward of DotScoring(normalize=True) is not built (the reference's "
+                                  "make_model never enables it, make_model.py:22)")
+    return _DotScoring.apply(u, c)

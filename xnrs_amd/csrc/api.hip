@@ -24,12 +24,15 @@ inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 struct Plan {
   int64_t chunk;  // sequences per pass
   size_t off_qkv, off_o, off_y, off_t, off_p, off_h;
+  size_t off_stats, off_a;  // training only: softmax row statistics, pooling weights
   size_t total;
 };
 
 // workspace carve for one chunk; every region 256-B aligned
-Plan make_plan(int64_t n_seq, int L, int D, int A, int E, bool att, bool additive, bool head, bool pooled, int64_t chunk) {
+Plan make_plan(int64_t n_seq, int L, int D, int A, int E, bool att, bool additive, bool head, bool pooled, int64_t chunk,
+               bool train = false, int n_heads = 0) {
   Plan p{};
+  if (train) chunk = n_seq > 0 ? n_seq : 1;  // the saved activations of the whole batch live in one carve
   if (chunk <= 0) chunk = 65536 / L;  // <= 64k token rows per pass: 512 full 128-row GEMM tiles (whole rounds of workgroups)
   if (chunk > n_seq) chunk = n_seq;
   if (chunk < 1) chunk = 1;
@@ -47,6 +50,8 @@ Plan make_plan(int64_t n_seq, int L, int D, int A, int E, bool att, bool additiv
   p.off_t = (pooled && additive) ? take(rows * (size_t)A) : 0;
   p.off_p = (pooled && head) ? take((size_t)chunk * D) : 0;
   p.off_h = (pooled && head) ? take((size_t)chunk * E) : 0;
+  p.off_stats = (train && att) ? take((size_t)chunk * n_heads * L * 2) : 0;
+  p.off_a = (train && additive) ? take(rows) : 0;
   p.total = off;
   return p;
 }
@@ -117,7 +122,7 @@ GemmArgs gemm1(const float* A, const int32_t* ids, int gS, int64_t lda, const fl
 int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n_seq, int L, int D,
                    const xnrs_mha_params* att, bool pooled, int pool_kind, const xnrs_additive_params* pool,
                    const xnrs_head_params* head, float* y, float* a_out, float* hm, int64_t chunk, void* ws,
-                   size_t ws_bytes, hipStream_t stream) {
+                   size_t ws_bytes, hipStream_t stream, bool train = false) {
   if (n_seq == 0) return XNRS_OK;
   if (n_seq < 0 || L <= 0 || D <= 0 || !x || !y) return XNRS_EINVAL;
   if (att) {
@@ -136,9 +141,12 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
   if (ids && !m && pooled && pool_kind == XNRS_POOL_MEAN) return XNRS_EINVAL;
   const int A = additive ? pool->hidden : 0;
   const int E = (pooled && head) ? head->out_features : D;
-  const Plan p = make_plan(n_seq, L, D, A, E, att != nullptr, additive, pooled && head, pooled, chunk);
+  const Plan p = make_plan(n_seq, L, D, A, E, att != nullptr, additive, pooled && head, pooled, chunk, train,
+                           att ? att->n_heads : 0);
   if (p.total > ws_bytes || (p.total > 0 && !ws)) return XNRS_EWORKSPACE;
   char* w = static_cast<char*>(ws);
+  float* stats = (train && att) ? reinterpret_cast<float*>(w + p.off_stats) : nullptr;
+  float* a_save = (train && additive) ? reinterpret_cast<float*>(w + p.off_a) : nullptr;
   float* qkv = reinterpret_cast<float*>(w + p.off_qkv);
   float* o = reinterpret_cast<float*>(w + p.off_o);
   float* yb = reinterpret_cast<float*>(w + p.off_y);
@@ -193,6 +201,7 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
       ma.scaled = att->scaled;
       ma.dropout_p = att->dropout_p;
       ma.seed = att->seed + (uint64_t)c0 * 0x9E3779B97F4A7C15ull;
+      ma.stats = stats;
       {
         ProfScope ps(1, 4.0 * rows * (double)L * D, stream);
         XNRS_TRY(launch_mha_core(ma, stream));
@@ -225,7 +234,7 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
       pa.x = seq;
       pa.ldx = D;
       pa.y = pooled_dst;
-      pa.a_out = a_out ? a_out + c0 * (int64_t)L : nullptr;
+      pa.a_out = a_save ? a_save : (a_out ? a_out + c0 * (int64_t)L : nullptr);
       pa.hm_out = cm ? hm_dst : nullptr;
       pa.n_seq = nc;
       pa.N = L;
@@ -235,6 +244,8 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
         ProfScope ps(4, 2.0 * rows * (double)(A + D), stream);
         XNRS_TRY(launch_additive_pool(pa, stream));
       }
+      if (a_save && a_out)
+        XNRS_TRY(hipMemcpyAsync(a_out, a_save, (size_t)rows * sizeof(float), hipMemcpyDeviceToDevice, stream));
     } else {
       MeanPoolArgs mp{};
       mp.x = seq;
@@ -386,6 +397,317 @@ int32_t xnrs_dot_scoring_fwd(const float* u, const float* c, float* r, int64_t B
                              void* stream) {
   if (!u || !c || !r || B < 0 || C <= 0 || E <= 0) return XNRS_EINVAL;
   return hip_rc(launch_dot_scoring(u, c, r, B, C, E, normalize, (hipStream_t)stream));
+}
+
+}  // extern "C"
+
+// =================================================================================================
+// training: forward with saved activations, backward
+// =================================================================================================
+namespace {
+
+struct BwdPlan {
+  size_t off_dh, off_dp, off_dseq, off_dpre, off_de, off_docat, off_dqkv, off_delta, off_slabs, off_colsum;
+  size_t total;
+};
+
+size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
+
+BwdPlan make_bwd_plan(int64_t n_seq, int L, int D, int A, int E, int n_heads, bool additive, bool head, bool pooled) {
+  BwdPlan p{};
+  const bool att = n_heads > 0;
+  const size_t rows = (size_t)n_seq * L;
+  size_t off = 0;
+  auto take = [&](size_t nbytes) {
+    size_t o = off;
+    off += align_up(nbytes);
+    return o;
+  };
+  p.off_dh = (pooled && head) ? take((size_t)n_seq * E * 4) : 0;
+  p.off_dp = (pooled && head) ? take((size_t)n_seq * D * 4) : 0;
+  p.off_dseq = (pooled) ? take(rows * D * 4) : 0;
+  p.off_dpre = additive ? take(rows * A * 4) : 0;
+  p.off_de = additive ? take(rows * 4) : 0;
+  p.off_docat = att ? take(rows * D * 4) : 0;
+  p.off_dqkv = att ? take(rows * 3 * D * 4) : 0;
+  p.off_delta = att ? take((size_t)n_seq * n_heads * L * 4) : 0;
+  // split-K slabs: the largest dW this pipeline produces
+  size_t slabs = 0;
+  if (att) slabs = max_sz(slabs, gemm_splitk_workspace_bytes(D, D, rows));
+  if (additive) slabs = max_sz(slabs, gemm_splitk_workspace_bytes(A, D, rows));
+  if (pooled && head) {
+    slabs = max_sz(slabs, gemm_splitk_workspace_bytes(E, D, n_seq));
+    slabs = max_sz(slabs, gemm_splitk_workspace_bytes(E, E, n_seq));
+  }
+  p.off_slabs = take(slabs);
+  int maxn = 3 * D;
+  if (A > maxn) maxn = A;
+  if (E > maxn) maxn = E;
+  p.off_colsum = take(colsum_workspace_bytes(maxn));
+  p.total = off;
+  return p;
+}
+
+// dW[N,K] = dY^T[N,M] . X[M,K]   (A k-major = dY, B k-major = X), split-K over the M rows
+hipError_t gemm_dw(const float* dY, int64_t lddy, const float* X, const int32_t* x_ids, int x_S, int64_t ldx, float* dW,
+                   int64_t M, int N, int K, float* slabs, hipStream_t stream) {
+  GemmArgs g{};
+  g.A = dY;
+  g.a_col = 1;
+  g.lda = lddy;
+  g.W[0] = X;
+  g.b_kn = 1;
+  g.b_gather_ids = x_ids;
+  g.b_gather_S = x_S;
+  g.ldw = ldx;
+  g.nseg = 1;
+  g.Nseg = K;
+  g.C = dW;
+  g.ldc = K;
+  g.M = N;
+  g.K = M;
+  const int ns = gemm_pick_splits(N, K, M);
+  if (ns > 1) {
+    g.slabs = slabs;
+    g.nsplit = ns;
+  }
+  return launch_gemm_f32(g, stream);
+}
+
+// dX[M,K] (+)= (dY[M,N] . W[N,K]) (*) f'(aux)
+hipError_t gemm_dx(const float* dY, int64_t lddy, const float* W, float* dX, int64_t lddx, int64_t M, int N, int K,
+                   const float* aux, int64_t ldaux, int aux_mode, int accumulate, hipStream_t stream) {
+  GemmArgs g{};
+  g.A = dY;
+  g.lda = lddy;
+  g.W[0] = W;
+  g.b_kn = 1;
+  g.ldw = K;
+  g.nseg = 1;
+  g.Nseg = K;
+  g.C = dX;
+  g.ldc = lddx;
+  g.M = M;
+  g.K = N;
+  g.aux = aux;
+  g.ldaux = ldaux;
+  g.aux_mode = aux_mode;
+  g.accumulate = accumulate;
+  return launch_gemm_f32(g, stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t xnrs_seq_encoder_saved_bytes(int64_t n_seq, int32_t L, int32_t D, int32_t A, int32_t E, int32_t n_heads,
+                                    int32_t pool_kind, int32_t has_head) {
+  const bool pooled = pool_kind != XNRS_POOL_NONE;
+  return make_plan(n_seq, L, D, A, E, n_heads > 0, pool_kind == XNRS_POOL_ADDITIVE, pooled && has_head, pooled, 0, true,
+                   n_heads)
+      .total;
+}
+
+int32_t xnrs_seq_encoder_fwd_train(const float* x, const float* m, const int32_t* ids, int64_t n_seq, int32_t L, int32_t D,
+                                   const xnrs_mha_params* att, int32_t pool_kind, const xnrs_additive_params* pool,
+                                   const xnrs_head_params* head, float* y, float* a_out, float* hm, void* saved,
+                                   size_t saved_bytes, void* stream) {
+  const bool pooled = pool_kind != XNRS_POOL_NONE;
+  return seq_encode(x, m, ids, n_seq, L, D, att, pooled, pool_kind, pool, pooled ? head : nullptr, y, a_out, hm, 0, saved,
+                    saved_bytes, (hipStream_t)stream, true);
+}
+
+size_t xnrs_seq_encoder_bwd_workspace_bytes(int64_t n_seq, int32_t L, int32_t D, int32_t A, int32_t E, int32_t n_heads,
+                                            int32_t pool_kind, int32_t has_head) {
+  const bool pooled = pool_kind != XNRS_POOL_NONE;
+  return make_bwd_plan(n_seq, L, D, A, E, n_heads, pool_kind == XNRS_POOL_ADDITIVE, pooled && has_head, pooled).total;
+}
+
+int32_t xnrs_seq_encoder_bwd(const float* x, const float* m, const int32_t* ids, int64_t n_seq, int32_t L, int32_t D,
+                             const xnrs_mha_params* att, int32_t pool_kind, const xnrs_additive_params* pool,
+                             const xnrs_head_params* head, const void* saved, size_t saved_bytes, const float* dy, float* dx,
+                             const xnrs_mha_grads* g_att, const xnrs_additive_grads* g_pool, const xnrs_head_grads* g_head,
+                             void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_seq == 0) return XNRS_OK;
+  if (n_seq < 0 || L <= 0 || D <= 0 || !x || !dy) return XNRS_EINVAL;
+  if (ids && dx) return XNRS_EINVAL;
+  const bool pooled = pool_kind != XNRS_POOL_NONE;
+  const bool additive = pool_kind == XNRS_POOL_ADDITIVE;
+  if (!pooled) head = nullptr;
+  if (att && D % att->n_heads != 0) return XNRS_EHEADS;
+  if (additive && !pool) return XNRS_EINVAL;
+  if (pool_kind == XNRS_POOL_MEAN && !m) return XNRS_EINVAL;
+  const int A = additive ? pool->hidden : 0;
+  const int E = head ? head->out_features : D;
+  const int nh = att ? att->n_heads : 0;
+  const Plan sp = make_plan(n_seq, L, D, A, E, att != nullptr, additive, head != nullptr, pooled, 0, true, nh);
+  if (sp.total > saved_bytes || (sp.total > 0 && !saved)) return XNRS_EWORKSPACE;
+  const BwdPlan bp = make_bwd_plan(n_seq, L, D, A, E, nh, additive, head != nullptr, pooled);
+  if (bp.total > ws_bytes || (bp.total > 0 && !ws)) return XNRS_EWORKSPACE;
+  const char* sv = static_cast<const char*>(saved);
+  const float* qkv = reinterpret_cast<const float*>(sv + sp.off_qkv);
+  const float* o = reinterpret_cast<const float*>(sv + sp.off_o);
+  const float* yatt = reinterpret_cast<const float*>(sv + sp.off_y);
+  const float* t = reinterpret_cast<const float*>(sv + sp.off_t);
+  const float* pb = reinterpret_cast<const float*>(sv + sp.off_p);
+  const float* hb = reinterpret_cast<const float*>(sv + sp.off_h);
+  const float* stats = reinterpret_cast<const float*>(sv + sp.off_stats);
+  const float* a_sv = reinterpret_cast<const float*>(sv + sp.off_a);
+  char* w = static_cast<char*>(ws);
+  float* dh = reinterpret_cast<float*>(w + bp.off_dh);
+  float* dp = reinterpret_cast<float*>(w + bp.off_dp);
+  float* dseq = reinterpret_cast<float*>(w + bp.off_dseq);
+  float* dpre = reinterpret_cast<float*>(w + bp.off_dpre);
+  float* de = reinterpret_cast<float*>(w + bp.off_de);
+  float* docat = reinterpret_cast<float*>(w + bp.off_docat);
+  float* dqkv = reinterpret_cast<float*>(w + bp.off_dqkv);
+  float* delta = reinterpret_cast<float*>(w + bp.off_delta);
+  float* slabs = reinterpret_cast<float*>(w + bp.off_slabs);
+  float* csum = reinterpret_cast<float*>(w + bp.off_colsum);
+  const int64_t rows = n_seq * L;
+
+  // gradient w.r.t. the sequence rows that fed the pooler (att output, or x itself)
+  const float* dseq_src = nullptr;  // [rows, D]
+  if (pooled) {
+    // ---- head: y = W2 relu(W0 p + b0) + b2
+    const float* dpool = dy;  // [n_seq, D]
+    if (head) {
+      if (g_head && g_head->w2) XNRS_TRY(gemm_dw(dy, E, hb, nullptr, 0, E, g_head->w2, n_seq, E, E, slabs, stream));
+      if (g_head && g_head->b2) XNRS_TRY(launch_colsum(dy, E, nullptr, n_seq, E, g_head->b2, csum, stream));
+      XNRS_TRY(gemm_dx(dy, E, head->w2, dh, E, n_seq, E, E, hb, E, /*relu'*/ 2, 0, stream));
+      if (g_head && g_head->w0) XNRS_TRY(gemm_dw(dh, E, pb, nullptr, 0, D, g_head->w0, n_seq, E, D, slabs, stream));
+      if (g_head && g_head->b0) XNRS_TRY(launch_colsum(dh, E, nullptr, n_seq, E, g_head->b0, csum, stream));
+      XNRS_TRY(gemm_dx(dh, E, head->w0, dp, D, n_seq, E, D, nullptr, 0, 0, 0, stream));
+      dpool = dp;
+    }
+    // ---- pooler
+    const float* seq = att ? yatt : x;
+    const int32_t* seq_ids = att ? nullptr : ids;
+    const bool need_dseq = att || dx;
+    float* dseq_dst = att ? dseq : dx;  // no attention stage: the sequence rows ARE x
+    if (additive) {
+      AdditivePoolBwdArgs pa{};
+      pa.dp = dpool;
+      pa.x = seq;
+      pa.ldx = D;
+      pa.x_gather_ids = seq_ids;
+      pa.a = a_sv;
+      pa.t = t;
+      pa.w2 = pool->w2;
+      pa.dx = need_dseq ? dseq_dst : nullptr;
+      pa.lddx = D;
+      pa.dpre = dpre;
+      pa.de = de;
+      pa.n_seq = n_seq;
+      pa.N = L;
+      pa.D = D;
+      pa.A = A;
+      XNRS_TRY(launch_additive_pool_bwd(pa, stream));
+      if (g_pool && g_pool->w2) XNRS_TRY(launch_colsum(t, A, de, rows, A, g_pool->w2, csum, stream));
+      if (g_pool && g_pool->b2) XNRS_TRY(launch_colsum(de, 1, nullptr, rows, 1, g_pool->b2, csum, stream));
+      if (g_pool && g_pool->w1) XNRS_TRY(gemm_dw(dpre, A, seq, seq_ids, L, D, g_pool->w1, rows, A, D, slabs, stream));
+      if (g_pool && g_pool->b1) XNRS_TRY(launch_colsum(dpre, A, nullptr, rows, A, g_pool->b1, csum, stream));
+      if (need_dseq) XNRS_TRY(gemm_dx(dpre, A, pool->w1, dseq_dst, D, rows, A, D, nullptr, 0, 0, /*accumulate*/ 1, stream));
+    } else if (need_dseq) {
+      XNRS_TRY(launch_mean_pool_bwd(dpool, m, ids, dseq_dst, D, n_seq, L, D, stream));
+    }
+    dseq_src = dseq_dst;
+  } else {
+    dseq_src = dy;  // MultiHeadAttention alone: dy is the gradient of the attention output
+  }
+  if (!att) return XNRS_OK;
+
+  // ---- out projection: yatt = O Wo^T + bo
+  if (g_att && g_att->wo) XNRS_TRY(gemm_dw(dseq_src, D, o, nullptr, 0, D, g_att->wo, rows, D, D, slabs, stream));
+  if (g_att && g_att->bo) XNRS_TRY(launch_colsum(dseq_src, D, nullptr, rows, D, g_att->bo, csum, stream));
+  XNRS_TRY(gemm_dx(dseq_src, D, att->wo, docat, D, rows, D, D, nullptr, 0, 0, 0, stream));
+  // ---- attention core
+  MhaBwdArgs mb{};
+  mb.q = qkv;
+  mb.k = qkv + D;
+  mb.v = qkv + 2 * (int64_t)D;
+  mb.ld = 3 * (int64_t)D;
+  mb.mask = m;
+  mb.mask_gather_ids = ids;
+  mb.o = o;
+  mb.ldo = D;
+  mb.d_o = docat;
+  mb.lddo = D;
+  mb.stats = stats;
+  mb.delta = delta;
+  mb.dq = dqkv;
+  mb.dk = dqkv + D;
+  mb.dv = dqkv + 2 * (int64_t)D;
+  mb.ldd = 3 * (int64_t)D;
+  mb.n_seq = n_seq;
+  mb.S = L;
+  mb.n_heads = nh;
+  mb.d_k = D / nh;
+  mb.scaled = att->scaled;
+  mb.dropout_p = att->dropout_p;
+  mb.seed = att->seed;
+  XNRS_TRY(launch_mha_bwd(mb, stream));
+  // ---- Q/K/V projections
+  float* gw[3] = {g_att ? g_att->wq : nullptr, g_att ? g_att->wk : nullptr, g_att ? g_att->wv : nullptr};
+  float* gb[3] = {g_att ? g_att->bq : nullptr, g_att ? g_att->bk : nullptr, g_att ? g_att->bv : nullptr};
+  const float* wqkv[3] = {att->wq, att->wk, att->wv};
+  for (int s3 = 0; s3 < 3; ++s3) {
+    const float* dpart = dqkv + (int64_t)s3 * D;
+    if (gw[s3]) XNRS_TRY(gemm_dw(dpart, 3 * (int64_t)D, x, ids, L, D, gw[s3], rows, D, D, slabs, stream));
+    if (gb[s3]) XNRS_TRY(launch_colsum(dpart, 3 * (int64_t)D, nullptr, rows, D, gb[s3], csum, stream));
+    if (dx) XNRS_TRY(gemm_dx(dpart, 3 * (int64_t)D, wqkv[s3], dx, D, rows, D, D, nullptr, 0, 0, s3 > 0 ? 1 : 0, stream));
+  }
+  return XNRS_OK;
+}
+
+size_t xnrs_linear_bwd_workspace_bytes(int64_t M, int32_t N, int32_t K) {
+  return align_up(gemm_splitk_workspace_bytes(N, K, M)) + align_up(colsum_workspace_bytes(N));
+}
+
+int32_t xnrs_linear_bwd(const float* x, const int32_t* gather_ids, int32_t gather_S, const float* w, const float* dy,
+                        float* dx, float* dw, float* db, int64_t M, int32_t N, int32_t K, void* ws, size_t ws_bytes,
+                        void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (M == 0) return XNRS_OK;
+  if (!x || !w || !dy || M < 0 || N <= 0 || K <= 0) return XNRS_EINVAL;
+  if (gather_ids && (dx || gather_S <= 0)) return XNRS_EINVAL;
+  const size_t s1 = align_up(gemm_splitk_workspace_bytes(N, K, M));
+  if (s1 + align_up(colsum_workspace_bytes(N)) > ws_bytes || !ws) return XNRS_EWORKSPACE;
+  float* slabs = static_cast<float*>(ws);
+  float* csum = reinterpret_cast<float*>(static_cast<char*>(ws) + s1);
+  if (dw) XNRS_TRY(gemm_dw(dy, N, x, gather_ids, gather_S, K, dw, M, N, K, slabs, stream));
+  if (db) XNRS_TRY(launch_colsum(dy, N, nullptr, M, N, db, csum, stream));
+  if (dx) XNRS_TRY(gemm_dx(dy, N, w, dx, K, M, N, K, nullptr, 0, 0, 0, stream));
+  return XNRS_OK;
+}
+
+size_t xnrs_embedding_linear_bwd_workspace_bytes(int64_t M, int32_t N, int32_t K) {
+  return xnrs_linear_bwd_workspace_bytes(M, N, K) + align_up((size_t)M * K * sizeof(float));
+}
+
+int32_t xnrs_embedding_linear_bwd(const float* table, const int32_t* ids, const float* w, const float* dy, float* d_table,
+                                  float* dw, float* db, int64_t M, int32_t N, int32_t K, int32_t n_rows, void* ws,
+                                  size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (M == 0) return XNRS_OK;
+  if (!table || !ids || !w || !dy || M < 0 || N <= 0 || K <= 0 || n_rows <= 0) return XNRS_EINVAL;
+  const size_t s1 = xnrs_linear_bwd_workspace_bytes(M, N, K);
+  if (s1 + align_up((size_t)M * K * sizeof(float)) > ws_bytes || !ws) return XNRS_EWORKSPACE;
+  int32_t rc = xnrs_linear_bwd(table, ids, 1, w, dy, nullptr, dw, db, M, N, K, ws, s1, stream_);
+  if (rc != XNRS_OK) return rc;
+  if (d_table) {
+    float* d_rows = reinterpret_cast<float*>(static_cast<char*>(ws) + s1);
+    XNRS_TRY(gemm_dx(dy, N, w, d_rows, K, M, N, K, nullptr, 0, 0, 0, stream));
+    XNRS_TRY(launch_embedding_grad(d_rows, ids, M, K, d_table, n_rows, stream));
+  }
+  return XNRS_OK;
+}
+
+int32_t xnrs_dot_scoring_bwd(const float* u, const float* c, const float* dr, float* du, float* dc, int64_t B, int32_t C,
+                             int32_t E, void* stream) {
+  if (!u || !c || !dr || B < 0 || C <= 0 || E <= 0) return XNRS_EINVAL;
+  return hip_rc(launch_dot_scoring_bwd(u, c, dr, du, dc, B, C, E, (hipStream_t)stream));
 }
 
 }  // extern "C"

@@ -29,23 +29,49 @@
 //   * split-K (dW: the contraction is the token-row count, the output is a small weight matrix):
 //     each k-slice writes its own fp32 slab; a second kernel sums the slabs in a fixed order
 //     (bitwise reproducible, no float atomics).
+#include <cstdlib>
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace xnrs {
 
-constexpr int BK = 32;
-constexpr int LDK = BK + 4;  // padded row of a k-contiguous LDS tile (144 B, 16-B aligned)
+constexpr int KALIGN = 32;  // split-K slices are aligned to the largest K tile
 
-template <int TM, int TN, bool A_COL, bool B_KN, bool VEC>
+// Out-of-range lanes of a tile load read this zero line instead of being zeroed AFTER the load: the
+// select is on the ADDRESS, so no instruction depends on the loaded data until the LDS store and the
+// loads of two tiles can stay in flight (a select on the data makes hipcc wait right behind the load).
+__device__ __attribute__((aligned(16))) float g_zero_line[4] = {0.f, 0.f, 0.f, 0.f};
+
+// PIPE selects the software pipeline:
+//   1: 2 LDS buffers; loads of tile t+1 fly during the MFMAs of tile t, LDS store + barrier at the end
+//   2: 2 LDS buffers, 2 register sets; tile t+2 is loaded while tile t+1 waits in registers, LDS store
+//      in the middle of the MFMA stream
+//   3: 3 LDS buffers; tile t+1 is ALREADY complete in LDS when iteration t starts, tile t+2 is loaded
+//      and stored during iteration t behind a barrier placed mid-stream, so the loop boundary carries
+//      no barrier and the MFMA stream runs from one tile into the next without draining
+// BUF: tile loads are raw buffer loads (ROW/WT layouts, no gather, operands <= 1 GB): the row offset is a
+// loop-invariant 32-bit VGPR, the k offset rides in the scalar offset, and out-of-range rows / k chunks
+// are handled by the hardware bounds check (offset bit 30 set -> beyond num_records -> returns 0).  The
+// loop then carries ~10 VALU instructions per K tile instead of ~50 (64-bit adds + address selects).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned BUF_OOB = 0x40000000u;
+
+template <int TM, int TN, bool A_COL, bool B_KN, bool VEC, int PIPE, int BK, bool BUF = false>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a, int m_tiles, int n_tiles_seg) {
+  static_assert(!BUF || (!A_COL && !B_KN && VEC), "buffer loads are implemented for the forward layout");
   constexpr int BM = 64 * TM, BN = 64 * TN;
-  constexpr int AR = BM / 32, BR = BN / 32;  // 16-byte chunks per thread per operand tile
+  constexpr int LDK = BK + 4;  // padded row of a k-contiguous LDS tile (16-B aligned; conflict-free b128 reads)
+  constexpr int CHK = BK / 4;  // 16-byte chunks per k-contiguous row
+  constexpr int RPP = 256 / CHK;  // rows per staging pass
+  constexpr int AR = BM / RPP, BR = BN / RPP;  // 16-byte chunks per thread per operand tile
   constexpr int LDA = A_COL ? (BM + 4) : LDK;
   constexpr int LDB = B_KN ? (BN + 4) : LDK;
   constexpr int A_SZ = A_COL ? BK * LDA : BM * LDA;
   constexpr int B_SZ = B_KN ? BK * LDB : BN * LDB;
-  __shared__ __attribute__((aligned(16))) float As[2][A_SZ];
-  __shared__ __attribute__((aligned(16))) float Bs[2][B_SZ];
+  constexpr int NBUF = PIPE == 3 ? 3 : 2;
+  __shared__ __attribute__((aligned(16))) float As[NBUF][A_SZ];
+  __shared__ __attribute__((aligned(16))) float Bs[NBUF][B_SZ];
 
   // ---- XCD-aware tile order (bijective for any grid size); blockIdx.y = k slice
   const int nwg = gridDim.x;
@@ -73,127 +99,180 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a, int m_tile
   const int wm = wave >> 1, wn = wave & 1;
 
   // ---- staging maps
-  // k-contiguous tile: chunk lc (4 floats of k) of row lr + 32*i
-  const int lc = tid & 7, lr = tid >> 3;
+  // k-contiguous tile: chunk lc (4 floats of k) of row lr + RPP*i
+  const int lc = tid % CHK, lr = tid / CHK;
   // k-major tile: chunk (4 floats along i) cA of k-row kA + KROWS*i
   constexpr int CHA = BM / 4, KRA = 256 / CHA;  // chunks per k-row, k-rows per pass
   constexpr int CHB = BN / 4, KRB = 256 / CHB;
   const int cA = tid % CHA, kA = tid / CHA;
   const int cB = tid % CHB, kB = tid / CHB;
 
+  // Every global load is unconditional (out-of-range lanes are pointed at g_zero_line), so the compiler's
+  // vmcnt bookkeeping stays exact and the two-tiles-ahead pipeline below really leaves a whole tile in
+  // flight across the LDS store.
   const float* pa[AR];
   const float* pb[BR];
-  if (!A_COL) {
+  unsigned a_ok = 0, b_ok = 0;  // bit i: row / column i of this thread is inside the matrix
+  unsigned offA[AR], offB[BR];  // BUF: byte offset of (row, chunk lc), or BUF_OOB
+  __amdgpu_buffer_rsrc_t rsA, rsB;
+  if constexpr (BUF) {
+    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, (int)(a.M * a.lda * 4), 0x00020000);
+    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, (int)((int64_t)a.Nseg * a.ldw * 4), 0x00020000);
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-      const int64_t gr = m0 + lr + 32 * i;
-      pa[i] = nullptr;
-      if (gr < a.M) {
-        int64_t src = gr;
-        if (a.gather_ids) {
-          const int64_t n = gr / a.gather_S;
-          src = (int64_t)a.gather_ids[n] * a.gather_S + (gr - n * a.gather_S);
-        }
-        pa[i] = a.A + src * a.lda + 4 * lc;
-      }
+      const int64_t gr = m0 + lr + RPP * i;
+      offA[i] = gr < a.M ? (unsigned)((gr * a.lda + 4 * lc) * 4) : BUF_OOB;
     }
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      const int col = n0 + lr + RPP * i;
+      offB[i] = col < a.Nseg ? (unsigned)(((int64_t)col * a.ldw + 4 * lc) * 4) : BUF_OOB;
+    }
+  } else if (!A_COL) {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      int64_t gr = m0 + lr + RPP * i;
+      if (gr < a.M) a_ok |= 1u << i;
+      else gr = a.M - 1;
+      int64_t src = gr;
+      if (a.gather_ids) {
+        const int64_t n = gr / a.gather_S;
+        src = (int64_t)a.gather_ids[n] * a.gather_S + (gr - n * a.gather_S);
+      }
+      pa[i] = a.A + src * a.lda;
+    }
+  } else {
+    if (m0 + 4 * cA < a.M) a_ok = 1;
   }
   if (!B_KN) {
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
-      const int col = n0 + lr + 32 * i;
-      pb[i] = (col < a.Nseg) ? (W + (int64_t)col * a.ldw + 4 * lc) : nullptr;
+      int col = n0 + lr + RPP * i;
+      if (col < a.Nseg) b_ok |= 1u << i;
+      else col = a.Nseg - 1;
+      pb[i] = W + (int64_t)col * a.ldw;
     }
+  } else {
+    if (n0 + 4 * cB < a.Nseg) b_ok = 1;
   }
 
-  f32x4 ra[AR], rb[BR];
-  auto gload = [&](int64_t k0) {
+  f32x4 ra[2][AR], rb[2][BR];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // P = register set (compile-time), k0 = first k of the tile
+  // `only` >= 0 restricts the call to ONE 16-byte chunk (A chunks 0..AR-1, then B chunks): the interleaved
+  // pipeline issues the tile loads / LDS stores one at a time between MFMAs.
+  auto gload = [&](auto P, int64_t k0, int only = -1) {
+    constexpr int p = decltype(P)::value;
+    if constexpr (BUF) {
+      const unsigned sel = (k0 + 4 * lc < kend) ? 0u : BUF_OOB;  // k tail of the last tile
+      const int soff = (int)(k0 * 4);
+#pragma unroll
+      for (int i = 0; i < AR; ++i)
+        if (only < 0 || only == i)
+          ra[p][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)(offA[i] | sel), soff, 0));
+#pragma unroll
+      for (int i = 0; i < BR; ++i)
+        if (only < 0 || only == AR + i)
+          rb[p][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(offB[i] | sel), soff, 0));
+      return;
+    }
     if (!A_COL) {
       const int64_t k = k0 + 4 * lc;
+      const bool kok = k < kend;
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (pa[i]) {
-          if (VEC) {
-            if (k < kend) v = *reinterpret_cast<const f32x4*>(pa[i] + k0);
-          } else {
+        if (only >= 0 && only != i) continue;
+        if (VEC) {
+          ra[p][i] = *reinterpret_cast<const f32x4*>((kok && ((a_ok >> i) & 1u)) ? pa[i] + k : g_zero_line);
+        } else {
+          f32x4 v = zero4;
+          if ((a_ok >> i) & 1u) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              if (k + e < kend) v[e] = pa[i][k0 + e];
+              if (k + e < kend) v[e] = pa[i][k + e];
           }
+          ra[p][i] = v;
         }
-        ra[i] = v;
       }
     } else {
       const int64_t mi = m0 + 4 * cA;
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
+        if (only >= 0 && only != i) continue;
         const int64_t k = k0 + kA + KRA * i;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (k < kend) {
-          const float* p = a.A + k * a.lda + mi;
-          if (VEC) {
-            if (mi < a.M) v = *reinterpret_cast<const f32x4*>(p);
-          } else {
+        const bool kok = k < kend;
+        const float* ptr = a.A + (kok ? k : kbeg) * a.lda;
+        if (VEC) {
+          ra[p][i] = *reinterpret_cast<const f32x4*>((kok && a_ok) ? ptr + mi : g_zero_line);
+        } else {
+          f32x4 v = zero4;
+          if (kok) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              if (mi + e < a.M) v[e] = p[e];
+              if (mi + e < a.M) v[e] = ptr[mi + e];
           }
+          ra[p][i] = v;
         }
-        ra[i] = v;
       }
     }
     if (!B_KN) {
       const int64_t k = k0 + 4 * lc;
+      const bool kok = k < kend;
 #pragma unroll
       for (int i = 0; i < BR; ++i) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (pb[i]) {
-          if (VEC) {
-            if (k < kend) v = *reinterpret_cast<const f32x4*>(pb[i] + k0);
-          } else {
+        if (only >= 0 && only != AR + i) continue;
+        if (VEC) {
+          rb[p][i] = *reinterpret_cast<const f32x4*>((kok && ((b_ok >> i) & 1u)) ? pb[i] + k : g_zero_line);
+        } else {
+          f32x4 v = zero4;
+          if ((b_ok >> i) & 1u) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              if (k + e < kend) v[e] = pb[i][k0 + e];
+              if (k + e < kend) v[e] = pb[i][k + e];
           }
+          rb[p][i] = v;
         }
-        rb[i] = v;
       }
     } else {
       const int ni = n0 + 4 * cB;
 #pragma unroll
       for (int i = 0; i < BR; ++i) {
+        if (only >= 0 && only != AR + i) continue;
         const int64_t k = k0 + kB + KRB * i;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (k < kend) {
-          int64_t src = k;
-          if (a.b_gather_ids) {
-            const int64_t n = k / a.b_gather_S;
-            src = (int64_t)a.b_gather_ids[n] * a.b_gather_S + (k - n * a.b_gather_S);
-          }
-          const float* p = W + src * a.ldw + ni;
-          if (VEC) {
-            if (ni < a.Nseg) v = *reinterpret_cast<const f32x4*>(p);
-          } else {
+        const bool kok = k < kend;
+        int64_t src = kok ? k : kbeg;
+        if (a.b_gather_ids) {
+          const int64_t n = src / a.b_gather_S;
+          src = (int64_t)a.b_gather_ids[n] * a.b_gather_S + (src - n * a.b_gather_S);
+        }
+        const float* ptr = W + src * a.ldw;
+        if (VEC) {
+          rb[p][i] = *reinterpret_cast<const f32x4*>((kok && b_ok) ? ptr + ni : g_zero_line);
+        } else {
+          f32x4 v = zero4;
+          if (kok) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              if (ni + e < a.Nseg) v[e] = p[e];
+              if (ni + e < a.Nseg) v[e] = ptr[ni + e];
           }
+          rb[p][i] = v;
         }
-        rb[i] = v;
       }
     }
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](auto P, int buf, int only = -1) {
+    constexpr int p = decltype(P)::value;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-      if (!A_COL) *reinterpret_cast<f32x4*>(&As[buf][(lr + 32 * i) * LDA + 4 * lc]) = ra[i];
-      else *reinterpret_cast<f32x4*>(&As[buf][(kA + KRA * i) * LDA + 4 * cA]) = ra[i];
+      if (only >= 0 && only != i) continue;
+      if (!A_COL) *reinterpret_cast<f32x4*>(&As[buf][(lr + RPP * i) * LDA + 4 * lc]) = ra[p][i];
+      else *reinterpret_cast<f32x4*>(&As[buf][(kA + KRA * i) * LDA + 4 * cA]) = ra[p][i];
     }
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
-      if (!B_KN) *reinterpret_cast<f32x4*>(&Bs[buf][(lr + 32 * i) * LDB + 4 * lc]) = rb[i];
-      else *reinterpret_cast<f32x4*>(&Bs[buf][(kB + KRB * i) * LDB + 4 * cB]) = rb[i];
+      if (only >= 0 && only != AR + i) continue;
+      if (!B_KN) *reinterpret_cast<f32x4*>(&Bs[buf][(lr + RPP * i) * LDB + 4 * lc]) = rb[p][i];
+      else *reinterpret_cast<f32x4*>(&Bs[buf][(kB + KRB * i) * LDB + 4 * cB]) = rb[p][i];
     }
   };
 
@@ -210,17 +289,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a, int m_tile
   const int a_row0 = wm * 32 * TM + frow;
   const int b_row0 = wn * 32 * TN + frow;
 
-  const int nk = (int)((kend - kbeg + BK - 1) / BK);
-  if (nk > 0) {
-    gload(kbeg);
-    sstore(0);
-  }
-  __syncthreads();
-  for (int t = 0; t < nk; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < nk) gload(kbeg + (int64_t)(t + 1) * BK);
+  // MFMAs of the 8-wide k groups [KQ0, KQ1) of the tile in LDS buffer `buf`
+  auto compute = [&](int buf, auto KQ0, auto KQ1) {
 #pragma unroll
-    for (int kq = 0; kq < BK / 8; ++kq) {
+    for (int kq = decltype(KQ0)::value; kq < decltype(KQ1)::value; ++kq) {
       f32x4 fa[TM], fb[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -248,8 +320,264 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a, int m_tile
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
     }
-    if (t + 1 < nk) sstore(buf ^ 1);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, BK / 16>;
+  using I4 = std::integral_constant<int, BK / 8>;
+
+  const int nk = (int)((kend - kbeg + BK - 1) / BK);
+  auto ktile = [&](int t) { return kbeg + (int64_t)t * BK; };
+  if constexpr (PIPE == 1) {
+    // one tile ahead: loads of tile t+1 fly during the MFMAs of tile t, LDS store at the end
+    if (nk > 0) {
+      gload(I0{}, ktile(0));
+      sstore(I0{}, 0);
+    }
     __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+      const int buf = t & 1;
+      if (t + 1 < nk) gload(I0{}, ktile(t + 1));
+      compute(buf, I0{}, I4{});
+      if (t + 1 < nk) sstore(I0{}, buf ^ 1);
+      __syncthreads();
+    }
+  } else if constexpr (PIPE == 4) {
+    // PIPE 2 with an explicitly INTERLEAVED instruction stream.  Measured with in-kernel cycle stamps
+    // (tools/diag_gemm.hip): after each barrier the 4 waves of a workgroup issue their 8 tile loads and 8
+    // ds_write_b128 back to back; the shared TA / LDS-write paths drain those bursts in ~500 cycles each
+    // and an in-order wave cannot issue its next MFMA while it is stuck behind them (~1100 of every
+    // ~5400 cycles).  Here the K tile is cut into slots of TM*TN MFMAs (one k step); after each slot at
+    // most ONE tile load, ONE LDS store and the fragment reads of the next k group are issued, and a
+    // sched_barrier pins that order: every memory instruction has >= 256 cycles of matrix work to drain
+    // behind.  Fragments are double-buffered so their LDS latency is covered by a whole k group.
+    constexpr int NKQ = BK / 8;
+    constexpr int NSLOT = NKQ * 4;
+    static_assert(AR + BR <= NSLOT / 2 + 2, "not enough slots for the tile loads");
+    f32x4 fa[2][TM], fb[2][TN];
+    auto ldfrag = [&](int st, int buf, int kq) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (!A_COL) {
+          fa[st][i] = *reinterpret_cast<const f32x4*>(&As[buf][(a_row0 + 32 * i) * LDA + kq * 8 + fk]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) fa[st][i][e] = As[buf][(kq * 8 + fk + e) * LDA + a_row0 + 32 * i];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (!B_KN) {
+          fb[st][j] = *reinterpret_cast<const f32x4*>(&Bs[buf][(b_row0 + 32 * j) * LDB + kq * 8 + fk]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) fb[st][j][e] = Bs[buf][(kq * 8 + fk + e) * LDB + b_row0 + 32 * j];
+        }
+      }
+    };
+    const int last = nk - 1;
+    if (nk > 0) {
+      gload(I0{}, ktile(0));
+      sstore(I0{}, 0);
+      gload(I1{}, ktile(1 < last ? 1 : last));
+    }
+    __syncthreads();
+    auto tile_body = [&](auto CUR, auto NXT, int buf, int t) {
+      // tile t is in LDS buffer `buf`; register set NXT holds tile t+1 (loaded one iteration ago) and is
+      // stored to the other buffer; register set CUR is reloaded with tile t+2.  All unconditional: at the
+      // tail the redundant loads / stores touch a tile / buffer nobody reads again.
+      const int64_t kn = ktile(t + 2 < last ? t + 2 : last);
+      ldfrag(0, buf, 0);
+#pragma unroll
+      for (int kq = 0; kq < NKQ; ++kq) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int slot = kq * 4 + e;
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kq & 1][i][e], fb[kq & 1][j][e], acc[i][j], 0, 0, 0);
+          if (e == 0 && kq + 1 < NKQ) ldfrag((kq + 1) & 1, buf, kq + 1);
+          if (slot < AR + BR) gload(CUR, kn, slot);
+          if (slot >= 2 && slot < 2 + AR + BR) sstore(NXT, buf ^ 1, slot - 2);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();
+    };
+    for (int t = 0; t < nk; t += 2) {
+      tile_body(I0{}, I1{}, 0, t);
+      if (t + 1 >= nk) break;
+      tile_body(I1{}, I0{}, 1, t + 1);
+    }
+  } else if constexpr (PIPE == 5) {
+    // Two LDS buffers, ONE register set, ONE loop body, interleaved stream (see PIPE 3 for the why):
+    // during iteration t the registers hold tile t+1 (loaded during iteration t-1); chunk j is stored to
+    // the other LDS buffer behind slot j+1 and reloaded with tile t+2 behind slot j+2.  The barrier at the
+    // end of the iteration publishes tile t+1 and frees the buffer of tile t.
+    constexpr int NKQ = BK / 8;
+    constexpr int NSLOT = NKQ * 4;
+    constexpr int NCH = AR + BR;
+    static_assert(NCH + 2 <= NSLOT, "not enough slots for the tile stores/loads");
+    f32x4 fa[2][TM], fb[2][TN];
+    auto ldfrag = [&](int st, int buf, int kq) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (!A_COL) {
+          fa[st][i] = *reinterpret_cast<const f32x4*>(&As[buf][(a_row0 + 32 * i) * LDA + kq * 8 + fk]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) fa[st][i][e] = As[buf][(kq * 8 + fk + e) * LDA + a_row0 + 32 * i];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (!B_KN) {
+          fb[st][j] = *reinterpret_cast<const f32x4*>(&Bs[buf][(b_row0 + 32 * j) * LDB + kq * 8 + fk]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) fb[st][j][e] = Bs[buf][(kq * 8 + fk + e) * LDB + b_row0 + 32 * j];
+        }
+      }
+    };
+    const int last = nk - 1;
+    if (nk > 0) {
+      gload(I0{}, ktile(0));
+      sstore(I0{}, 0);
+      gload(I0{}, ktile(1 < last ? 1 : last));
+    }
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+      const int buf = t & 1;
+      const int64_t kn = ktile(t + 2 < last ? t + 2 : last);
+      ldfrag(0, buf, 0);
+#pragma unroll
+      for (int kq = 0; kq < NKQ; ++kq) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int slot = kq * 4 + e;
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kq & 1][i][e], fb[kq & 1][j][e], acc[i][j], 0, 0, 0);
+          if (e == 1 && kq + 1 < NKQ) ldfrag((kq + 1) & 1, buf, kq + 1);
+          if (slot >= 1 && slot < 1 + NCH) sstore(I0{}, buf ^ 1, slot - 1);  // tile t+1 -> LDS (redundant at the tail)
+          if (slot >= 2 && slot < 2 + NCH) gload(I0{}, kn, slot - 2);        // tile t+2 -> the register just stored
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();
+    }
+  } else if constexpr (PIPE == 3) {
+    // Three LDS buffers, ONE register set, ONE loop body, explicitly interleaved instruction stream:
+    //   tile t   : being multiplied            (LDS buffer b0)
+    //   tile t+1 : complete in LDS             (b1)  -> its first fragments are prefetched BEFORE the loop
+    //                                                   boundary, the MFMA stream never drains
+    //   tile t+2 : in registers (loaded during iteration t-1); stored to b2, one 16-byte chunk per slot,
+    //              behind this iteration's barrier
+    //   tile t+3 : each register chunk is reloaded one slot after it was stored
+    // A "slot" = the TM*TN MFMAs of one k step (256 matrix cycles); behind each slot at most one LDS store,
+    // one tile load and the fragment reads of the next k group are issued and a sched_barrier pins the
+    // order.  Why: in-kernel cycle stamps (tools/diag_gemm.hip) showed that issuing the 8 loads / 8
+    // ds_write_b128 of a tile back to back (all 4 waves at once, right after the barrier) blocks an
+    // in-order wave for ~1100 of every ~5400 cycles while the shared TA / LDS-write paths drain.
+    // One barrier per K tile after slot 0: once a wave is past it every wave has finished tile t-1 (the
+    // previous owner of b2); the stores become visible at the NEXT barrier, an iteration before their use.
+    constexpr int NKQ = BK / 8;
+    constexpr int NSLOT = NKQ * 4;
+    constexpr int NCH = AR + BR;
+    static_assert(NCH + 2 <= NSLOT, "not enough slots for the tile stores/loads");
+    f32x4 fa[2][TM], fb[2][TN];
+    auto ldfrag = [&](int st, int buf, int kq) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (!A_COL) {
+          fa[st][i] = *reinterpret_cast<const f32x4*>(&As[buf][(a_row0 + 32 * i) * LDA + kq * 8 + fk]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) fa[st][i][e] = As[buf][(kq * 8 + fk + e) * LDA + a_row0 + 32 * i];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (!B_KN) {
+          fb[st][j] = *reinterpret_cast<const f32x4*>(&Bs[buf][(b_row0 + 32 * j) * LDB + kq * 8 + fk]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) fb[st][j][e] = Bs[buf][(kq * 8 + fk + e) * LDB + b_row0 + 32 * j];
+        }
+      }
+    };
+    const int last = nk - 1;
+    if (nk > 0) {
+      gload(I0{}, ktile(0));
+      sstore(I0{}, 0);
+      gload(I0{}, ktile(1 < last ? 1 : last));
+      sstore(I0{}, 1);
+      gload(I0{}, ktile(2 < last ? 2 : last));
+    }
+    __syncthreads();
+    int b0 = 0, b1 = 1, b2 = 2;  // buffers of tiles t, t+1, t+2
+    if (nk > 0) ldfrag(0, b0, 0);
+    for (int t = 0; t < nk; ++t) {
+      const int64_t kn = ktile(t + 3 < last ? t + 3 : last);
+#pragma unroll
+      for (int kq = 0; kq < NKQ; ++kq) {
+        constexpr int dummy = 0;
+        (void)dummy;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int slot = kq * 4 + e;
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kq & 1][i][e], fb[kq & 1][j][e], acc[i][j], 0, 0, 0);
+          if (slot == 0) __syncthreads();
+          if (e == 1) {  // fragments of the next k group (of this tile, or the first group of tile t+1)
+            if (kq + 1 < NKQ) ldfrag((kq + 1) & 1, b0, kq + 1);
+            else ldfrag((kq + 1) & 1, b1, 0);
+          }
+          if (slot >= 1 && slot < 1 + NCH) sstore(I0{}, b2, slot - 1);   // tile t+2 -> LDS (redundant at the tail)
+          if (slot >= 2 && slot < 2 + NCH) gload(I0{}, kn, slot - 2);    // tile t+3 -> the register just stored
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      const int tmp = b0;
+      b0 = b1;
+      b1 = b2;
+      b2 = tmp;
+    }
+  } else {
+    // two tiles ahead (two named register sets): at iteration t tile t+1 already sits in registers
+    // (issued one iteration ago) and tile t+2 is issued now; the LDS store of tile t+1 goes in the
+    // MIDDLE of the MFMA stream, so neither the load latency nor the ds_write issue is exposed at
+    // the barrier.
+    // Loads are issued UNCONDITIONALLY (tile index clamped to the last tile, redundant tail loads are
+    // simply never stored): a load under `if (t + 2 < nk)` makes the number of outstanding loads
+    // path-dependent and hipcc then waits for the NEW tile too before the LDS store.
+    const int last = nk - 1;
+    if (nk > 0) {
+      gload(I0{}, ktile(0));
+      sstore(I0{}, 0);
+      gload(I1{}, ktile(1 < last ? 1 : last));
+    }
+    __syncthreads();
+    for (int t = 0; t < nk; t += 2) {
+      gload(I0{}, ktile(t + 2 < last ? t + 2 : last));
+      compute(0, I0{}, I2{});
+      if (t + 1 < nk) sstore(I1{}, 1);
+      compute(0, I2{}, I4{});
+      __syncthreads();
+      if (t + 1 >= nk) break;
+      gload(I1{}, ktile(t + 3 < last ? t + 3 : last));
+      compute(1, I0{}, I2{});
+      if (t + 2 < nk) sstore(I0{}, 0);
+      compute(1, I2{}, I4{});
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -305,10 +633,42 @@ static hipError_t launch_cfg(const GemmArgs& a, bool vec, int nsplit, hipStream_
   const int64_t grid = m_tiles * n_tiles_seg * a.nseg;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
   const dim3 g((unsigned)grid, (unsigned)nsplit);
-  if (vec)
-    hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, A_COL, B_KN, true>), g, dim3(256), 0, stream, a, (int)m_tiles, n_tiles_seg);
-  else
-    hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, A_COL, B_KN, false>), g, dim3(256), 0, stream, a, (int)m_tiles, n_tiles_seg);
+  // development knobs for in-process A/B runs (tools/bench_gemm.py): XNRS_GEMM_PIPE=1|2|3, XNRS_GEMM_BK=16|32
+  const char* pe = getenv("XNRS_GEMM_PIPE");
+  const char* be = getenv("XNRS_GEMM_BK");
+  const int pipe = pe ? (pe[0] - '0') : 2;
+  const int bk = (be && be[0] == '1') ? 16 : 32;
+#define XNRS_LAUNCH(VECV, PIPEV, BKV, BUFV)                                                                       \
+  hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, A_COL, B_KN, VECV, PIPEV, BKV, BUFV>), g, dim3(256), 0, stream, a,      \
+                     (int)m_tiles, n_tiles_seg)
+  const char* ue = getenv("XNRS_GEMM_BUF");
+  bool buf = !(ue && ue[0] == '0') && vec && !a.gather_ids && a.M * a.lda * 4 <= (int64_t)BUF_OOB &&
+             (int64_t)a.Nseg * a.ldw * 4 <= (int64_t)BUF_OOB;
+  if (!vec) XNRS_LAUNCH(false, 1, 32, false);
+  else if constexpr (TM == 2 && TN == 2 && !A_COL && !B_KN) {  // variants are only built for the forward main tile
+    if (buf) {
+      if (pipe == 3 && bk == 16) XNRS_LAUNCH(true, 3, 16, true);
+      else if (pipe == 3) XNRS_LAUNCH(true, 3, 32, true);
+      else if (pipe == 1 && bk == 16) XNRS_LAUNCH(true, 1, 16, true);
+      else if (pipe == 1) XNRS_LAUNCH(true, 1, 32, true);
+      else if (pipe == 4) XNRS_LAUNCH(true, 4, 32, true);
+      else if (pipe == 5 && bk == 16) XNRS_LAUNCH(true, 5, 16, true);
+      else if (pipe == 5) XNRS_LAUNCH(true, 5, 32, true);
+      else XNRS_LAUNCH(true, 2, 32, true);
+    } else {
+      if (pipe == 3 && bk == 16) XNRS_LAUNCH(true, 3, 16, false);
+      else if (pipe == 3) XNRS_LAUNCH(true, 3, 32, false);
+      else if (pipe == 1 && bk == 16) XNRS_LAUNCH(true, 1, 16, false);
+      else if (pipe == 1) XNRS_LAUNCH(true, 1, 32, false);
+      else if (pipe == 4) XNRS_LAUNCH(true, 4, 32, false);
+      else if (pipe == 5 && bk == 16) XNRS_LAUNCH(true, 5, 16, false);
+      else if (pipe == 5) XNRS_LAUNCH(true, 5, 32, false);
+      else XNRS_LAUNCH(true, 2, 32, false);
+    }
+  } else {
+    XNRS_LAUNCH(true, 2, 32, false);
+  }
+#undef XNRS_LAUNCH
   return hipGetLastError();
 }
 
@@ -367,7 +727,7 @@ hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t stream) {
   int nsplit = 1;
   if (a.slabs && a.nsplit > 1) {
     nsplit = a.nsplit;
-    const int64_t per = ((a.K + nsplit - 1) / nsplit + BK - 1) / BK * BK;  // BK-aligned slices
+    const int64_t per = ((a.K + nsplit - 1) / nsplit + KALIGN - 1) / KALIGN * KALIGN;  // tile-aligned slices
     a.k_per_split = per;
     nsplit = (int)((a.K + per - 1) / per);
     a.slab_stride = a.M * a.ldc;

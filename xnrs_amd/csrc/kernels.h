@@ -41,6 +41,7 @@ struct GemmArgs {
   int32_t nsplit;
   int64_t k_per_split;  // filled in by the launcher
   int64_t slab_stride;  // filled in by the launcher
+  unsigned long long* diag;  // diagnostic builds only (XNRS_GEMM_DIAG): per-wave segment cycle totals
 };
 int gemm_pick_splits(int64_t M, int64_t N, int64_t K);
 size_t gemm_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
@@ -158,6 +159,9 @@ hipError_t launch_colsum(const float* X, int64_t ldx, const float* w, int64_t M,
                          hipStream_t stream);
 hipError_t launch_dot_scoring_bwd(const float* u, const float* c, const float* dr, float* du, float* dc, int64_t B, int32_t C,
                                   int32_t E, hipStream_t stream);
+
+hipError_t launch_embedding_grad(const float* d_rows, const int32_t* ids, int64_t M, int K, float* d_table, int n_rows,
+                                 hipStream_t stream);
 
 hipError_t launch_collapse_mask(const float* m, const int32_t* gather_ids, float* hm, int64_t n_rows, int32_t S,
                                 hipStream_t stream);

@@ -176,3 +176,29 @@ hipError_t launch_dot_scoring_bwd(const float* u, const float* c, const float* d
 }
 
 }  // namespace xnrs
+
+namespace xnrs {
+
+// d_table[r, :] = sum over m with ids[m] == r of d_rows[m, :]   (nn.Embedding backward for the small
+// category tables of NAML, naml.py:82-86).  One block per table row scans the ids in order: deterministic,
+// no atomics; O(n_rows * M) index compares is negligible for tables of tens to hundreds of rows.
+__global__ __launch_bounds__(64) void embedding_grad_kernel(const float* d_rows, const int32_t* ids, int64_t M, int K,
+                                                             float* d_table) {
+  const int r = blockIdx.x;
+  for (int k0 = 0; k0 < K; k0 += 64) {
+    const int k = k0 + threadIdx.x;
+    float acc = 0.f;
+    for (int64_t m = 0; m < M; ++m)
+      if (ids[m] == r && k < K) acc += d_rows[m * K + k];
+    if (k < K) d_table[(int64_t)r * K + k] = acc;
+  }
+}
+
+hipError_t launch_embedding_grad(const float* d_rows, const int32_t* ids, int64_t M, int K, float* d_table, int n_rows,
+                                 hipStream_t stream) {
+  if (n_rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(embedding_grad_kernel, dim3((unsigned)n_rows), dim3(64), 0, stream, d_rows, ids, M, K, d_table);
+  return hipGetLastError();
+}
+
+}  // namespace xnrs

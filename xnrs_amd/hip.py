@@ -24,7 +24,11 @@ SYMBOLS = (
     "xnrs_additive_workspace_bytes", "xnrs_additive_attention_fwd", "xnrs_masked_mean_fwd", "xnrs_collapse_mask",
     "xnrs_text_encoder_workspace_bytes", "xnrs_text_encoder_fwd", "xnrs_user_encoder_workspace_bytes",
     "xnrs_user_encoder_fwd", "xnrs_dot_scoring_fwd", "xnrs_profile_enable", "xnrs_profile_read",
+    "xnrs_seq_encoder_saved_bytes", "xnrs_seq_encoder_fwd_train", "xnrs_seq_encoder_bwd_workspace_bytes",
+    "xnrs_seq_encoder_bwd", "xnrs_linear_bwd_workspace_bytes", "xnrs_linear_bwd",
+    "xnrs_embedding_linear_bwd_workspace_bytes", "xnrs_embedding_linear_bwd", "xnrs_dot_scoring_bwd",
 )
+POOL_NONE = -1
 PROFILE_STAGES = ("qkv_gemm", "attention_core", "out_gemm", "fc1_tanh_gemm", "pool", "head_gemms")
 
 
@@ -43,6 +47,18 @@ class AdditiveParams(C.Structure):
 
 class HeadParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w0", "b0", "w2", "b2")] + [("out_features", C.c_int32)]
+
+
+class MhaGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo")]
+
+
+class AdditiveGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w1", "b1", "w2", "b2")]
+
+
+class HeadGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w0", "b0", "w2", "b2")]
 
 
 _lib = None
@@ -89,6 +105,27 @@ def lib():
                                         C.POINTER(HeadParams), p, p, p, sz, p]
     l.xnrs_dot_scoring_fwd.restype = i32
     l.xnrs_dot_scoring_fwd.argtypes = [p, p, p, i64, i32, i32, i32, p]
+    l.xnrs_seq_encoder_saved_bytes.restype = sz
+    l.xnrs_seq_encoder_saved_bytes.argtypes = [i64, i32, i32, i32, i32, i32, i32, i32]
+    l.xnrs_seq_encoder_fwd_train.restype = i32
+    l.xnrs_seq_encoder_fwd_train.argtypes = [p, p, p, i64, i32, i32, C.POINTER(MhaParams), i32, C.POINTER(AdditiveParams),
+                                             C.POINTER(HeadParams), p, p, p, p, sz, p]
+    l.xnrs_seq_encoder_bwd_workspace_bytes.restype = sz
+    l.xnrs_seq_encoder_bwd_workspace_bytes.argtypes = [i64, i32, i32, i32, i32, i32, i32, i32]
+    l.xnrs_seq_encoder_bwd.restype = i32
+    l.xnrs_seq_encoder_bwd.argtypes = [p, p, p, i64, i32, i32, C.POINTER(MhaParams), i32, C.POINTER(AdditiveParams),
+                                       C.POINTER(HeadParams), p, sz, p, p, C.POINTER(MhaGrads), C.POINTER(AdditiveGrads),
+                                       C.POINTER(HeadGrads), p, sz, p]
+    l.xnrs_linear_bwd_workspace_bytes.restype = sz
+    l.xnrs_linear_bwd_workspace_bytes.argtypes = [i64, i32, i32]
+    l.xnrs_linear_bwd.restype = i32
+    l.xnrs_linear_bwd.argtypes = [p, p, i32, p, p, p, p, p, i64, i32, i32, p, sz, p]
+    l.xnrs_embedding_linear_bwd_workspace_bytes.restype = sz
+    l.xnrs_embedding_linear_bwd_workspace_bytes.argtypes = [i64, i32, i32]
+    l.xnrs_embedding_linear_bwd.restype = i32
+    l.xnrs_embedding_linear_bwd.argtypes = [p, p, p, p, p, p, p, i64, i32, i32, i32, p, sz, p]
+    l.xnrs_dot_scoring_bwd.restype = i32
+    l.xnrs_dot_scoring_bwd.argtypes = [p, p, p, p, p, i64, i32, i32, p]
     l.xnrs_profile_enable.restype = i32
     l.xnrs_profile_enable.argtypes = [C.c_uint32]
     l.xnrs_profile_read.restype = i32
@@ -179,12 +216,8 @@ def additive_params(pool):
 
 
 def head_params(head):
-    """nn.Sequential(Linear, act, Linear) -> HeadParams (the activation must be ReLU)."""
+    """nn.Sequential(Linear, ReLU, Linear) -> (HeadParams, keepalive list); biases may be absent."""
     l0, l2 = head[0], head[2]
     ts = [dev_f32(l0.weight, "head.0.weight"), None if l0.bias is None else dev_f32(l0.bias, "head.0.bias"),
           dev_f32(l2.weight, "head.2.weight"), None if l2.bias is None else dev_f32(l2.bias, "head.2.bias")]
-    p = HeadParams(*[0 if t is None else t.data_ptr() for t in ts], l0.out_features)
-    for i in (1, 3):
-        if ts[i] is None:
-            setattr(p, ("w0", "b0", "w2", "b2")[i], None)
-    return p, ts
+    return HeadParams(*[None if t is None else t.data_ptr() for t in ts], l0.out_features), ts

@@ -25,6 +25,10 @@ def _mask2d(m: Optional[torch.Tensor], rows: int, cols: int, what: str) -> Optio
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = hip.ACT_NONE):
     """nn.Linear forward (+ fused activation) on the fp32 MFMA GEMM.  x:(..., K) -> (..., N)."""
+    if act == hip.ACT_NONE and torch.is_grad_enabled() and any(
+            t is not None and t.requires_grad for t in (x, weight, bias)):
+        from . import autograd
+        return autograd.linear(x, weight, bias)
     x = hip.dev_f32(x, "linear input")
     w = hip.dev_f32(weight, "linear weight")
     b = None if bias is None else hip.dev_f32(bias, "linear bias")
@@ -77,6 +81,9 @@ def additive_forward(x: torch.Tensor, m: Optional[torch.Tensor], pool, return_we
 
 def masked_mean(x: torch.Tensor, m: torch.Tensor):
     """layers.MaskedMean.forward (layers.py:26-37).  x:(B,N,D), m:(B,N,1) -> (B,1,D)."""
+    if torch.is_grad_enabled() and isinstance(x, torch.Tensor) and x.requires_grad:
+        from . import autograd
+        return autograd.masked_mean(x, m)
     x = hip.dev_f32(x, "masked_mean input")
     B, N, D = x.shape
     m2 = _mask2d(m, B, N, "masked_mean mask")
@@ -177,6 +184,13 @@ def user_encoder_forward(x: torch.Tensor, m: torch.Tensor, att, pooler, head, re
 
 def dot_scoring(u: torch.Tensor, c: torch.Tensor, normalize: bool = False):
     """DotScoring.forward (scoring.py:12-23).  u:(B,1,E), c:(B,C,E) -> (B,C,1)."""
+    if torch.is_grad_enabled() and (getattr(u, "requires_grad", False) or getattr(c, "requires_grad", False)):
+        from . import autograd
+        return autograd.dot_scoring(u, c, normalize)
+    return dot_scoring_forward(u, c, normalize)
+
+
+def dot_scoring_forward(u: torch.Tensor, c: torch.Tensor, normalize: bool = False):
     u = hip.dev_f32(u, "user vector")
     c = hip.dev_f32(c, "candidate vectors")
     B, Cn, E = c.shape
