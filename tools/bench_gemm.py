@@ -14,7 +14,7 @@ from xnrs_amd import hip, ops  # noqa: E402
 
 dev = torch.device("cuda", 0)
 shapes = [(65500, 2304, 768), (65500, 768, 768), (30720, 960, 320)]
-names = sys.argv[1].split(",") if len(sys.argv) > 1 else ["p1k32g", "p2k32b", "p4k32b", "p3k32b", "p3k32g", "p3k16b", "p1k16b"]
+names = sys.argv[1].split(",") if len(sys.argv) > 1 else ["p1k32g", "p5k32b", "p5k16b", "p6k16b"]
 variants = {v: {"XNRS_GEMM_PIPE": v[1], "XNRS_GEMM_BK": v[3:5], "XNRS_GEMM_BUF": "1" if v[5] == "b" else "0"} for v in names}
 torch.manual_seed(0)
 for (M, N, K) in shapes:

@@ -44,12 +44,12 @@ constexpr int KALIGN = 32;  // split-K slices are aligned to the largest K tile
 __device__ __attribute__((aligned(16))) float g_zero_line[4] = {0.f, 0.f, 0.f, 0.f};
 
 // PIPE selects the software pipeline:
-//   1: 2 LDS buffers; loads of tile t+1 fly during the MFMAs of tile t, LDS store + barrier at the end
-//   2: 2 LDS buffers, 2 register sets; tile t+2 is loaded while tile t+1 waits in registers, LDS store
-//      in the middle of the MFMA stream
-//   3: 3 LDS buffers; tile t+1 is ALREADY complete in LDS when iteration t starts, tile t+2 is loaded
-//      and stored during iteration t behind a barrier placed mid-stream, so the loop boundary carries
-//      no barrier and the MFMA stream runs from one tile into the next without draining
+//   1: plain double buffering -- loads of tile t+1 fly during the MFMAs of tile t, LDS store + barrier at the
+//      end of the tile (used for the scalar-load fallback; 117 TF on the Q/K/V projection)
+//   5: the same two LDS buffers and ONE register set, but an explicitly interleaved instruction stream
+//      (default; 130-136 TF).  Measured alternatives that were dropped: two register sets / LDS store
+//      mid-stream without interleave 121 TF; three LDS buffers with cross-barrier fragment prefetch at one
+//      workgroup per CU 112 TF, at two per CU 130 TF.
 // BUF: tile loads are raw buffer loads (ROW/WT layouts, no gather, operands <= 1 GB): the row offset is a
 // loop-invariant 32-bit VGPR, the k offset rides in the scalar offset, and out-of-range rows / k chunks
 // are handled by the hardware bounds check (offset bit 30 set -> beyond num_records -> returns 0).  The
@@ -57,8 +57,8 @@ __device__ __attribute__((aligned(16))) float g_zero_line[4] = {0.f, 0.f, 0.f, 0
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned BUF_OOB = 0x40000000u;
 
-template <int TM, int TN, bool A_COL, bool B_KN, bool VEC, int PIPE, int BK, bool BUF = false>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a, int m_tiles, int n_tiles_seg) {
+template <int TM, int TN, bool A_COL, bool B_KN, bool VEC, int PIPE, int BK, bool BUF = false, int MINW = 2>
+__global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_tiles, int n_tiles_seg) {
   static_assert(!BUF || (!A_COL && !B_KN && VEC), "buffer loads are implemented for the forward layout");
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int LDK = BK + 4;  // padded row of a k-contiguous LDS tile (16-B aligned; conflict-free b128 reads)
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a, int m_tile
   constexpr int LDB = B_KN ? (BN + 4) : LDK;
   constexpr int A_SZ = A_COL ? BK * LDA : BM * LDA;
   constexpr int B_SZ = B_KN ? BK * LDB : BN * LDB;
-  constexpr int NBUF = PIPE == 3 ? 3 : 2;
+  constexpr int NBUF = 2;
   __shared__ __attribute__((aligned(16))) float As[NBUF][A_SZ];
   __shared__ __attribute__((aligned(16))) float Bs[NBUF][B_SZ];
 
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a, int m_tile
     if (n0 + 4 * cB < a.Nseg) b_ok = 1;
   }
 
-  f32x4 ra[2][AR], rb[2][BR];
+  f32x4 ra[1][AR], rb[1][BR];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   // P = register set (compile-time), k0 = first k of the tile
   // `only` >= 0 restricts the call to ONE 16-byte chunk (A chunks 0..AR-1, then B chunks): the interleaved
@@ -322,8 +322,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a, int m_tile
     }
   };
   using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, BK / 16>;
   using I4 = std::integral_constant<int, BK / 8>;
 
   const int nk = (int)((kend - kbeg + BK - 1) / BK);
@@ -342,80 +340,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a, int m_tile
       if (t + 1 < nk) sstore(I0{}, buf ^ 1);
       __syncthreads();
     }
-  } else if constexpr (PIPE == 4) {
-    // PIPE 2 with an explicitly INTERLEAVED instruction stream.  Measured with in-kernel cycle stamps
-    // (tools/diag_gemm.hip): after each barrier the 4 waves of a workgroup issue their 8 tile loads and 8
-    // ds_write_b128 back to back; the shared TA / LDS-write paths drain those bursts in ~500 cycles each
-    // and an in-order wave cannot issue its next MFMA while it is stuck behind them (~1100 of every
-    // ~5400 cycles).  Here the K tile is cut into slots of TM*TN MFMAs (one k step); after each slot at
-    // most ONE tile load, ONE LDS store and the fragment reads of the next k group are issued, and a
-    // sched_barrier pins that order: every memory instruction has >= 256 cycles of matrix work to drain
-    // behind.  Fragments are double-buffered so their LDS latency is covered by a whole k group.
-    constexpr int NKQ = BK / 8;
-    constexpr int NSLOT = NKQ * 4;
-    static_assert(AR + BR <= NSLOT / 2 + 2, "not enough slots for the tile loads");
-    f32x4 fa[2][TM], fb[2][TN];
-    auto ldfrag = [&](int st, int buf, int kq) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        if (!A_COL) {
-          fa[st][i] = *reinterpret_cast<const f32x4*>(&As[buf][(a_row0 + 32 * i) * LDA + kq * 8 + fk]);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) fa[st][i][e] = As[buf][(kq * 8 + fk + e) * LDA + a_row0 + 32 * i];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        if (!B_KN) {
-          fb[st][j] = *reinterpret_cast<const f32x4*>(&Bs[buf][(b_row0 + 32 * j) * LDB + kq * 8 + fk]);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) fb[st][j][e] = Bs[buf][(kq * 8 + fk + e) * LDB + b_row0 + 32 * j];
-        }
-      }
-    };
-    const int last = nk - 1;
-    if (nk > 0) {
-      gload(I0{}, ktile(0));
-      sstore(I0{}, 0);
-      gload(I1{}, ktile(1 < last ? 1 : last));
-    }
-    __syncthreads();
-    auto tile_body = [&](auto CUR, auto NXT, int buf, int t) {
-      // tile t is in LDS buffer `buf`; register set NXT holds tile t+1 (loaded one iteration ago) and is
-      // stored to the other buffer; register set CUR is reloaded with tile t+2.  All unconditional: at the
-      // tail the redundant loads / stores touch a tile / buffer nobody reads again.
-      const int64_t kn = ktile(t + 2 < last ? t + 2 : last);
-      ldfrag(0, buf, 0);
-#pragma unroll
-      for (int kq = 0; kq < NKQ; ++kq) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int slot = kq * 4 + e;
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kq & 1][i][e], fb[kq & 1][j][e], acc[i][j], 0, 0, 0);
-          if (e == 0 && kq + 1 < NKQ) ldfrag((kq + 1) & 1, buf, kq + 1);
-          if (slot < AR + BR) gload(CUR, kn, slot);
-          if (slot >= 2 && slot < 2 + AR + BR) sstore(NXT, buf ^ 1, slot - 2);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      __syncthreads();
-    };
-    for (int t = 0; t < nk; t += 2) {
-      tile_body(I0{}, I1{}, 0, t);
-      if (t + 1 >= nk) break;
-      tile_body(I1{}, I0{}, 1, t + 1);
-    }
   } else if constexpr (PIPE == 5) {
-    // Two LDS buffers, ONE register set, ONE loop body, interleaved stream (see PIPE 3 for the why):
-    // during iteration t the registers hold tile t+1 (loaded during iteration t-1); chunk j is stored to
-    // the other LDS buffer behind slot j+1 and reloaded with tile t+2 behind slot j+2.  The barrier at the
-    // end of the iteration publishes tile t+1 and frees the buffer of tile t.
+    // Two LDS buffers, ONE register set, ONE loop body, explicitly interleaved instruction stream.
+    // Why: in-kernel cycle stamps (profiles/r01_gemm_stamps.txt) showed that issuing the 8 loads / 8
+    // ds_write_b128 of a tile back to back -- all 4 waves at once, right after the barrier -- blocks an
+    // in-order wave for ~1100 of every ~5400 cycles while the shared TA / LDS-write paths drain, and no
+    // MFMA of that wave can issue meanwhile.  Here a K tile is cut into "slots" of TM*TN MFMAs (one k
+    // step, 256 matrix cycles); behind each slot at most ONE LDS store, ONE tile load and the fragment
+    // reads of the next k group are issued, and a sched_barrier pins that order.
+    // During iteration t the registers hold tile t+1 (loaded during iteration t-1); chunk j is stored to
+    // the other LDS buffer behind slot j+1 and reloaded with tile t+2 behind slot j+2 (~a full iteration
+    // of latency hiding).  Fragments are double-buffered so their LDS latency hides behind a k group.  The
+    // barrier at the end of the iteration publishes tile t+1 and frees the buffer of tile t.
     constexpr int NKQ = BK / 8;
     constexpr int NSLOT = NKQ * 4;
     constexpr int NCH = AR + BR;
@@ -468,114 +404,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a, int m_tile
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      __syncthreads();
-    }
-  } else if constexpr (PIPE == 3) {
-    // Three LDS buffers, ONE register set, ONE loop body, explicitly interleaved instruction stream:
-    //   tile t   : being multiplied            (LDS buffer b0)
-    //   tile t+1 : complete in LDS             (b1)  -> its first fragments are prefetched BEFORE the loop
-    //                                                   boundary, the MFMA stream never drains
-    //   tile t+2 : in registers (loaded during iteration t-1); stored to b2, one 16-byte chunk per slot,
-    //              behind this iteration's barrier
-    //   tile t+3 : each register chunk is reloaded one slot after it was stored
-    // A "slot" = the TM*TN MFMAs of one k step (256 matrix cycles); behind each slot at most one LDS store,
-    // one tile load and the fragment reads of the next k group are issued and a sched_barrier pins the
-    // order.  Why: in-kernel cycle stamps (tools/diag_gemm.hip) showed that issuing the 8 loads / 8
-    // ds_write_b128 of a tile back to back (all 4 waves at once, right after the barrier) blocks an
-    // in-order wave for ~1100 of every ~5400 cycles while the shared TA / LDS-write paths drain.
-    // One barrier per K tile after slot 0: once a wave is past it every wave has finished tile t-1 (the
-    // previous owner of b2); the stores become visible at the NEXT barrier, an iteration before their use.
-    constexpr int NKQ = BK / 8;
-    constexpr int NSLOT = NKQ * 4;
-    constexpr int NCH = AR + BR;
-    static_assert(NCH + 2 <= NSLOT, "not enough slots for the tile stores/loads");
-    f32x4 fa[2][TM], fb[2][TN];
-    auto ldfrag = [&](int st, int buf, int kq) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        if (!A_COL) {
-          fa[st][i] = *reinterpret_cast<const f32x4*>(&As[buf][(a_row0 + 32 * i) * LDA + kq * 8 + fk]);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) fa[st][i][e] = As[buf][(kq * 8 + fk + e) * LDA + a_row0 + 32 * i];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        if (!B_KN) {
-          fb[st][j] = *reinterpret_cast<const f32x4*>(&Bs[buf][(b_row0 + 32 * j) * LDB + kq * 8 + fk]);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) fb[st][j][e] = Bs[buf][(kq * 8 + fk + e) * LDB + b_row0 + 32 * j];
-        }
-      }
-    };
-    const int last = nk - 1;
-    if (nk > 0) {
-      gload(I0{}, ktile(0));
-      sstore(I0{}, 0);
-      gload(I0{}, ktile(1 < last ? 1 : last));
-      sstore(I0{}, 1);
-      gload(I0{}, ktile(2 < last ? 2 : last));
-    }
-    __syncthreads();
-    int b0 = 0, b1 = 1, b2 = 2;  // buffers of tiles t, t+1, t+2
-    if (nk > 0) ldfrag(0, b0, 0);
-    for (int t = 0; t < nk; ++t) {
-      const int64_t kn = ktile(t + 3 < last ? t + 3 : last);
-#pragma unroll
-      for (int kq = 0; kq < NKQ; ++kq) {
-        constexpr int dummy = 0;
-        (void)dummy;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int slot = kq * 4 + e;
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kq & 1][i][e], fb[kq & 1][j][e], acc[i][j], 0, 0, 0);
-          if (slot == 0) __syncthreads();
-          if (e == 1) {  // fragments of the next k group (of this tile, or the first group of tile t+1)
-            if (kq + 1 < NKQ) ldfrag((kq + 1) & 1, b0, kq + 1);
-            else ldfrag((kq + 1) & 1, b1, 0);
-          }
-          if (slot >= 1 && slot < 1 + NCH) sstore(I0{}, b2, slot - 1);   // tile t+2 -> LDS (redundant at the tail)
-          if (slot >= 2 && slot < 2 + NCH) gload(I0{}, kn, slot - 2);    // tile t+3 -> the register just stored
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      const int tmp = b0;
-      b0 = b1;
-      b1 = b2;
-      b2 = tmp;
-    }
-  } else {
-    // two tiles ahead (two named register sets): at iteration t tile t+1 already sits in registers
-    // (issued one iteration ago) and tile t+2 is issued now; the LDS store of tile t+1 goes in the
-    // MIDDLE of the MFMA stream, so neither the load latency nor the ds_write issue is exposed at
-    // the barrier.
-    // Loads are issued UNCONDITIONALLY (tile index clamped to the last tile, redundant tail loads are
-    // simply never stored): a load under `if (t + 2 < nk)` makes the number of outstanding loads
-    // path-dependent and hipcc then waits for the NEW tile too before the LDS store.
-    const int last = nk - 1;
-    if (nk > 0) {
-      gload(I0{}, ktile(0));
-      sstore(I0{}, 0);
-      gload(I1{}, ktile(1 < last ? 1 : last));
-    }
-    __syncthreads();
-    for (int t = 0; t < nk; t += 2) {
-      gload(I0{}, ktile(t + 2 < last ? t + 2 : last));
-      compute(0, I0{}, I2{});
-      if (t + 1 < nk) sstore(I1{}, 1);
-      compute(0, I2{}, I4{});
-      __syncthreads();
-      if (t + 1 >= nk) break;
-      gload(I1{}, ktile(t + 3 < last ? t + 3 : last));
-      compute(1, I0{}, I2{});
-      if (t + 2 < nk) sstore(I0{}, 0);
-      compute(1, I2{}, I4{});
       __syncthreads();
     }
   }
@@ -633,40 +461,32 @@ static hipError_t launch_cfg(const GemmArgs& a, bool vec, int nsplit, hipStream_
   const int64_t grid = m_tiles * n_tiles_seg * a.nseg;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
   const dim3 g((unsigned)grid, (unsigned)nsplit);
-  // development knobs for in-process A/B runs (tools/bench_gemm.py): XNRS_GEMM_PIPE=1|2|3, XNRS_GEMM_BK=16|32
+  // development knobs for in-process A/B runs (tools/bench_gemm.py): XNRS_GEMM_PIPE=1|5|6, XNRS_GEMM_BK=16|32,
+  // XNRS_GEMM_BUF=0|1.  Default ("6"): PIPE 5, BK 16, registers capped for 4 workgroups per CU on the main tile.
   const char* pe = getenv("XNRS_GEMM_PIPE");
   const char* be = getenv("XNRS_GEMM_BK");
-  const int pipe = pe ? (pe[0] - '0') : 2;
-  const int bk = (be && be[0] == '1') ? 16 : 32;
-#define XNRS_LAUNCH(VECV, PIPEV, BKV, BUFV)                                                                       \
-  hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, A_COL, B_KN, VECV, PIPEV, BKV, BUFV>), g, dim3(256), 0, stream, a,      \
-                     (int)m_tiles, n_tiles_seg)
   const char* ue = getenv("XNRS_GEMM_BUF");
-  bool buf = !(ue && ue[0] == '0') && vec && !a.gather_ids && a.M * a.lda * 4 <= (int64_t)BUF_OOB &&
-             (int64_t)a.Nseg * a.ldw * 4 <= (int64_t)BUF_OOB;
-  if (!vec) XNRS_LAUNCH(false, 1, 32, false);
-  else if constexpr (TM == 2 && TN == 2 && !A_COL && !B_KN) {  // variants are only built for the forward main tile
-    if (buf) {
-      if (pipe == 3 && bk == 16) XNRS_LAUNCH(true, 3, 16, true);
-      else if (pipe == 3) XNRS_LAUNCH(true, 3, 32, true);
-      else if (pipe == 1 && bk == 16) XNRS_LAUNCH(true, 1, 16, true);
-      else if (pipe == 1) XNRS_LAUNCH(true, 1, 32, true);
-      else if (pipe == 4) XNRS_LAUNCH(true, 4, 32, true);
-      else if (pipe == 5 && bk == 16) XNRS_LAUNCH(true, 5, 16, true);
-      else if (pipe == 5) XNRS_LAUNCH(true, 5, 32, true);
-      else XNRS_LAUNCH(true, 2, 32, true);
-    } else {
-      if (pipe == 3 && bk == 16) XNRS_LAUNCH(true, 3, 16, false);
-      else if (pipe == 3) XNRS_LAUNCH(true, 3, 32, false);
-      else if (pipe == 1 && bk == 16) XNRS_LAUNCH(true, 1, 16, false);
-      else if (pipe == 1) XNRS_LAUNCH(true, 1, 32, false);
-      else if (pipe == 4) XNRS_LAUNCH(true, 4, 32, false);
-      else if (pipe == 5 && bk == 16) XNRS_LAUNCH(true, 5, 16, false);
-      else if (pipe == 5) XNRS_LAUNCH(true, 5, 32, false);
-      else XNRS_LAUNCH(true, 2, 32, false);
-    }
+  const int pipe = pe ? (pe[0] - '0') : 6;
+  const int bk = be ? ((be[0] == '1') ? 16 : 32) : 32;
+  const bool buf = !(ue && ue[0] == '0') && vec && !a.gather_ids && a.M * a.lda * 4 <= (int64_t)BUF_OOB &&
+                   (int64_t)a.Nseg * a.ldw * 4 <= (int64_t)BUF_OOB;
+#define XNRS_LAUNCH(VECV, PIPEV, BKV, BUFV, MINWV)                                                                  \
+  hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, A_COL, B_KN, VECV, PIPEV, BKV, BUFV, MINWV>), g, dim3(256), 0, stream, a, \
+                     (int)m_tiles, n_tiles_seg)
+  if (!vec) XNRS_LAUNCH(false, 1, 32, false, 2);
+  else if constexpr (TM == 2 && TN == 2 && !A_COL && !B_KN) {  // forward main tile: all variants are built
+    if (pipe == 1 && buf) XNRS_LAUNCH(true, 1, 32, true, 2);
+    else if (pipe == 1) XNRS_LAUNCH(true, 1, 32, false, 2);
+    else if (pipe == 5 && bk == 16 && buf) XNRS_LAUNCH(true, 5, 16, true, 2);
+    else if (pipe == 5 && buf) XNRS_LAUNCH(true, 5, 32, true, 2);
+    else if (pipe == 5) XNRS_LAUNCH(true, 5, 32, false, 2);
+    else if (buf) XNRS_LAUNCH(true, 5, 16, true, 4);
+    else XNRS_LAUNCH(true, 5, 16, false, 4);
+  } else if constexpr (!A_COL && !B_KN) {
+    if (buf) XNRS_LAUNCH(true, 5, 32, true, 2);
+    else XNRS_LAUNCH(true, 5, 32, false, 2);
   } else {
-    XNRS_LAUNCH(true, 2, 32, false);
+    XNRS_LAUNCH(true, 5, 32, false, 2);
   }
 #undef XNRS_LAUNCH
   return hipGetLastError();

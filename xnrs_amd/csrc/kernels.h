@@ -41,7 +41,6 @@ struct GemmArgs {
   int32_t nsplit;
   int64_t k_per_split;  // filled in by the launcher
   int64_t slab_stride;  // filled in by the launcher
-  unsigned long long* diag;  // diagnostic builds only (XNRS_GEMM_DIAG): per-wave segment cycle totals
 };
 int gemm_pick_splits(int64_t M, int64_t N, int64_t K);
 size_t gemm_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);

@@ -18,6 +18,8 @@
 //     16 consecutive floats.
 //   * the output comes out as O^T[dv = 16*dt + 4g + r][query c]: 4 consecutive dv per lane -> one
 //     16-byte store per lane straight into the (M, D) "concat heads" layout (layers.py:153).
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace xnrs {
@@ -163,6 +165,146 @@ __global__ __launch_bounds__(256) void mha_core_kernel(MhaCoreArgs a, int QT, in
   }
 }
 
+// Fast path (S <= 64, d_k <= 64, 16-byte aligned): one wave per (sequence, head).  K and V of the head
+// are fetched ONCE into registers in MFMA operand layout (K: 16-byte row fragments; V: the transposed
+// gather the second product needs) and all query tiles are swept against them, so the per-q-tile
+// traffic is only Q in and O out.  Same arithmetic, same order of operations per element as
+// mha_core_kernel (bitwise identical results).
+template <int KT, int NFB>
+__global__ __launch_bounds__(256) void mha_core_head_kernel(MhaCoreArgs a, int64_t n_units) {
+  const int lane = threadIdx.x & 63;
+  const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit >= n_units) return;  // wave-uniform
+  const int hd = (int)(unit % a.n_heads);
+  const int64_t seq = unit / a.n_heads;
+  const int c = lane & 15, g = lane >> 4;
+  const int S = a.S, dk = a.d_k;
+  const int64_t row0 = seq * S;
+  const int hoff = hd * dk;
+  const int ld = (int)a.ld;
+
+  // ---- K fragments: kf[kt][fb] = K[16kt + c][16fb + 4g .. +3]
+  const float* kbase = a.k + row0 * a.ld + hoff;
+  const float* vbase = a.v + row0 * a.ld + hoff;
+  f32x4 kf[KT][NFB];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    const int key = kt * 16 + c;
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) {
+      const int f0 = fb * 16 + 4 * g;
+      kf[kt][fb] = (key < S && f0 < dk) ? *reinterpret_cast<const f32x4*>(kbase + key * ld + f0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  // ---- V gather: vv[kt][dt][r] = V[16kt + 4g + r][16dt + c]
+  float vv[KT][NFB][4];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int dt = 0; dt < NFB; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + 4 * g + r;
+        const int dv = dt * 16 + c;
+        vv[kt][dt][r] = (key < S && dv < dk) ? vbase[key * ld + dv] : 0.f;
+      }
+
+  const int64_t mrow = a.mask ? (a.mask_gather_ids ? (int64_t)a.mask_gather_ids[seq] * S : row0) : 0;
+  const float sq = sqrtf((float)dk);
+  const float keep = 1.f - a.dropout_p;
+  const int QT = (S + 15) >> 4;
+  for (int qt = 0; qt < QT; ++qt) {
+    const int query = qt * 16 + c;
+    const bool qvalid = query < S;
+    const float* qrow = a.q + (row0 + (qvalid ? query : 0)) * a.ld + hoff;
+    f32x4 acc[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) {
+      const int f0 = fb * 16 + 4 * g;
+      const f32x4 qf = (qvalid && f0 < dk) ? *reinterpret_cast<const f32x4*>(qrow + f0) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][fb][e], qf[e], acc[kt], 0, 0, 0);
+    }
+    const float mq = (a.mask && qvalid) ? a.mask[mrow + query] : 1.f;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + 4 * g + r;
+        float sv = acc[kt][r];
+        if (a.scaled) sv = sv / sq;
+        if (mq == 0.f) sv = -1e9f;
+        if (key >= S) sv = -INFINITY;
+        acc[kt][r] = sv;
+        mx = fmaxf(mx, sv);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ev = expf(acc[kt][r] - mx);
+        acc[kt][r] = ev;
+        sum += ev;
+      }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    if (a.stats && qvalid && g == 0) {
+      float* st = a.stats + ((seq * a.n_heads + hd) * (int64_t)S + query) * 2;
+      st[0] = mx;
+      st[1] = sum;
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float p = acc[kt][r] / sum;
+        if (a.dropout_p > 0.f) {
+          const int key = kt * 16 + 4 * g + r;
+          const uint64_t idx = ((uint64_t)(seq * a.n_heads + hd) * S + (uint64_t)query) * S + (uint64_t)key;
+          p = (uniform01(a.seed, idx) < keep) ? p / keep : 0.f;
+        }
+        acc[kt][r] = p;
+      }
+#pragma unroll
+    for (int dt = 0; dt < NFB; ++dt) {
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[kt][dt][r], acc[kt][r], o, 0, 0, 0);
+      const int dv0 = dt * 16 + 4 * g;
+      if (qvalid && dv0 < dk) *reinterpret_cast<f32x4*>(a.out + (row0 + query) * a.ldo + hoff + dv0) = o;
+    }
+  }
+}
+
+template <int KT, int NFB>
+static hipError_t launch_head(const MhaCoreArgs& a, hipStream_t stream) {
+  const int64_t n_units = a.n_seq * a.n_heads;
+  const int64_t grid = (n_units + 3) / 4;
+  if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((mha_core_head_kernel<KT, NFB>), dim3((unsigned)grid), dim3(256), 0, stream, a, n_units);
+  return hipGetLastError();
+}
+
+template <int KT>
+static hipError_t launch_head_kt(const MhaCoreArgs& a, hipStream_t stream) {
+  switch ((a.d_k + 15) / 16) {
+    case 1: return launch_head<KT, 1>(a, stream);
+    case 2: return launch_head<KT, 2>(a, stream);
+    case 3: return launch_head<KT, 3>(a, stream);
+    default: return launch_head<KT, 4>(a, stream);
+  }
+}
+
 template <int KT>
 static hipError_t launch_kt(const MhaCoreArgs& a, bool vec, hipStream_t stream) {
   const int QT = (a.S + 15) / 16;
@@ -183,6 +325,16 @@ hipError_t launch_mha_core(const MhaCoreArgs& a, hipStream_t stream) {
                    ((reinterpret_cast<uintptr_t>(a.q) & 15) == 0) && ((reinterpret_cast<uintptr_t>(a.k) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0);
   const int KT = (a.S + 15) / 16;
+  const char* fe = getenv("XNRS_MHA_HEADWAVE");  // development knob for A/B runs; default on
+  const bool fast = vec && a.S <= 64 && a.d_k <= 64 && ((int64_t)a.n_seq * a.S * a.ld < (1ll << 31)) && !(fe && fe[0] == '0');
+  if (fast) {
+    switch (KT) {
+      case 1: return launch_head_kt<1>(a, stream);
+      case 2: return launch_head_kt<2>(a, stream);
+      case 3: return launch_head_kt<3>(a, stream);
+      default: return launch_head_kt<4>(a, stream);
+    }
+  }
   switch (KT) {
     case 1: return launch_kt<1>(a, vec, stream);
     case 2: return launch_kt<2>(a, vec, stream);
