@@ -48,8 +48,10 @@ Plan make_plan(int64_t n_seq, int L, int D, int A, int E, bool att, bool additiv
   p.off_o = att ? take(rows * (size_t)D) : 0;
   p.off_y = (att && pooled) ? take(rows * (size_t)D) : 0;  // att output when a pooler follows
   p.off_t = (pooled && additive) ? take(rows * (size_t)A) : 0;
-  p.off_p = (pooled && head) ? take((size_t)chunk * D) : 0;
-  p.off_h = (pooled && head) ? take((size_t)chunk * E) : 0;
+  // pooled vectors / head hidden of ALL sequences: the head runs once after the chunk loop (two GEMMs over
+  // n_seq rows instead of 2 x n_chunks launches of ~20 workgroups each)
+  p.off_p = (pooled && head) ? take((size_t)n_seq * D) : 0;
+  p.off_h = (pooled && head) ? take((size_t)n_seq * E) : 0;
   p.off_stats = (train && att) ? take((size_t)chunk * n_heads * L * 2) : 0;
   p.off_a = (train && additive) ? take(rows) : 0;
   p.total = off;
@@ -217,7 +219,7 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
     }
     if (!pooled) continue;
 
-    float* pooled_dst = head ? pb : y + c0 * (int64_t)D;
+    float* pooled_dst = (head ? pb : y) + c0 * (int64_t)D;
     float* hm_dst = hm ? hm + c0 : nullptr;
     if (additive) {
       {
@@ -263,13 +265,11 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
         XNRS_TRY(launch_mean_pool(mp, stream));
       }
     }
-    if (head) {
-      ProfScope ps(5, 2.0 * nc * ((double)D * E + (double)E * E), stream);
-      XNRS_TRY(launch_gemm_f32(gemm1(pb, nullptr, 0, D, head->w0, head->b0, hb, E, nc, E, D, XNRS_ACT_RELU), stream));
-      XNRS_TRY(launch_gemm_f32(gemm1(hb, nullptr, 0, E, head->w2, head->b2, y + c0 * (int64_t)E, E, nc, E, E,
-                                     XNRS_ACT_NONE),
-                               stream));
-    }
+  }
+  if (pooled && head) {
+    ProfScope ps(5, 2.0 * n_seq * ((double)D * E + (double)E * E), stream);
+    XNRS_TRY(launch_gemm_f32(gemm1(pb, nullptr, 0, D, head->w0, head->b0, hb, E, n_seq, E, D, XNRS_ACT_RELU), stream));
+    XNRS_TRY(launch_gemm_f32(gemm1(hb, nullptr, 0, E, head->w2, head->b2, y, E, n_seq, E, E, XNRS_ACT_NONE), stream));
   }
   return XNRS_OK;
 }

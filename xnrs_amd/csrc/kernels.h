@@ -91,6 +91,14 @@ struct MhaBwdArgs {
 };
 hipError_t launch_mha_bwd(const MhaBwdArgs& a, hipStream_t stream);
 
+// Softmax arithmetic shared by the attention forward and backward (they must agree bit for bit because
+// the backward RECOMPUTES P from the saved row max / row sum).  The scale is a multiply by 1/sqrt(d_k) and
+// the normalisation a multiply by 1/sum (one division per row instead of one per element), exp is the
+// hardware exp2 path: <= ~2e-7 relative per element against torch's division/expf -- far inside the 1e-4
+// parity bar -- and it takes the softmax from ~45 to ~10 VALU instructions per element (the attention
+// kernel was VALU-bound, not MFMA-bound).
+__device__ __forceinline__ float attn_exp(float x) { return __expf(x); }
+
 // counter-based RNG for attention dropout (training mode only): splitmix64 finaliser on
 // (seed, element index) -> uniform [0,1).  Parity with torch's CPU Philox stream is impossible
 // (SURVEY.md section 7 "hard parts"); only the distribution matters.  Forward and backward call this with

@@ -118,25 +118,24 @@ __global__ __launch_bounds__(256) void mha_dq_kernel(MhaBwdArgs a, int QT, int64
     sum = a.stats[2 * si + 1];
     delta = a.delta[si];
   }
-  const float sq = sqrtf((float)dk);
+  const float inv_sq = a.scaled ? 1.f / sqrtf((float)dk) : 1.f;
+  const float inv_sum = 1.f / sum;
   const float keep = 1.f - a.dropout_p;
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int key = kt * 16 + 4 * g + r;
-      float sv = s[kt][r];
-      if (a.scaled) sv = sv / sq;
+      const float sv = s[kt][r] * inv_sq;
       float ds = 0.f;
       if (mq != 0.f && key < S && qvalid) {
-        const float p = expf(sv - mx) / sum;
+        const float p = attn_exp(sv - mx) * inv_sum;
         float dpv = dp[kt][r];
         if (a.dropout_p > 0.f) {
           const uint64_t idx = ((uint64_t)(seq * a.n_heads + hd) * S + (uint64_t)query) * S + (uint64_t)key;
           dpv = (uniform01(a.seed, idx) < keep) ? dpv / keep : 0.f;
         }
-        ds = p * (dpv - delta);
-        if (a.scaled) ds = ds / sq;
+        ds = p * (dpv - delta) * inv_sq;
       }
       s[kt][r] = ds;
     }
@@ -180,7 +179,7 @@ __global__ __launch_bounds__(256) void mha_dkdv_kernel(MhaBwdArgs a, int KTn, in
   const float* krow = a.k + krow_i * a.ld + hoff;
   const float* vrow = a.v + krow_i * a.ld + hoff;
   const int nfb = (dk + 15) >> 4;
-  const float sq = sqrtf((float)dk);
+  const float inv_sq = a.scaled ? 1.f / sqrtf((float)dk) : 1.f;
   const float keep = 1.f - a.dropout_p;
   const int64_t mrow = a.mask ? (a.mask_gather_ids ? (int64_t)a.mask_gather_ids[seq] * S : row0) : 0;
   const int64_t sbase = (seq * a.n_heads + hd) * (int64_t)S;
@@ -225,10 +224,9 @@ __global__ __launch_bounds__(256) void mha_dkdv_kernel(MhaBwdArgs a, int KTn, in
         const float mx = a.stats[2 * (sbase + query)];
         const float sum = a.stats[2 * (sbase + query) + 1];
         const float delta = a.delta[sbase + query];
-        float sv = s[r];
-        if (a.scaled) sv = sv / sq;
+        float sv = s[r] * inv_sq;
         if (mq == 0.f) sv = -1e9f;
-        const float p = expf(sv - mx) / sum;
+        const float p = attn_exp(sv - mx) * (1.f / sum);
         float dpv = dp[r];
         pdv = p;
         if (a.dropout_p > 0.f) {
@@ -237,10 +235,7 @@ __global__ __launch_bounds__(256) void mha_dkdv_kernel(MhaBwdArgs a, int KTn, in
           pdv = kp ? p / keep : 0.f;
           dpv = kp ? dpv / keep : 0.f;
         }
-        if (mq != 0.f) {
-          dsv = p * (dpv - delta);
-          if (a.scaled) dsv = dsv / sq;
-        }
+        if (mq != 0.f) dsv = p * (dpv - delta) * inv_sq;
       }
       pd[r] = pdv;
       ds[r] = dsv;

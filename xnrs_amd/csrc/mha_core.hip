@@ -85,15 +85,14 @@ __global__ __launch_bounds__(256) void mha_core_kernel(MhaCoreArgs a, int QT, in
     const int64_t mrow = a.mask_gather_ids ? (int64_t)a.mask_gather_ids[seq] * S : row0;
     mq = a.mask[mrow + query];
   }
-  const float sq = sqrtf((float)dk);
+  const float inv_sq = a.scaled ? 1.f / sqrtf((float)dk) : 1.f;
   float mx = -INFINITY;
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int key = kt * 16 + 4 * g + r;
-      float s = acc[kt][r];
-      if (a.scaled) s = s / sq;
+      float s = acc[kt][r] * inv_sq;
       if (mq == 0.f) s = -1e9f;
       if (key >= S) s = -INFINITY;
       acc[kt][r] = s;
@@ -107,7 +106,7 @@ __global__ __launch_bounds__(256) void mha_core_kernel(MhaCoreArgs a, int QT, in
   for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float e = expf(acc[kt][r] - mx);  // exp(-inf) = 0 for padding keys
+      const float e = attn_exp(acc[kt][r] - mx);  // exp(-inf) = 0 for padding keys
       acc[kt][r] = e;
       sum += e;
     }
@@ -120,11 +119,12 @@ __global__ __launch_bounds__(256) void mha_core_kernel(MhaCoreArgs a, int QT, in
     st[1] = sum;
   }
   const float keep = 1.f - a.dropout_p;
+  const float inv_sum = 1.f / sum;
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float p = acc[kt][r] / sum;
+      float p = acc[kt][r] * inv_sum;
       if (a.dropout_p > 0.f) {  // nn.Dropout on the probabilities (layers.py:148), train mode only
         const int key = kt * 16 + 4 * g + r;
         const uint64_t idx = ((uint64_t)(seq * a.n_heads + hd) * S + (uint64_t)query) * S + (uint64_t)key;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void mha_core_head_kernel(MhaCoreArgs a, int64
       }
 
   const int64_t mrow = a.mask ? (a.mask_gather_ids ? (int64_t)a.mask_gather_ids[seq] * S : row0) : 0;
-  const float sq = sqrtf((float)dk);
+  const float inv_sq = a.scaled ? 1.f / sqrtf((float)dk) : 1.f;
   const float keep = 1.f - a.dropout_p;
   const int QT = (S + 15) >> 4;
   for (int qt = 0; qt < QT; ++qt) {
@@ -236,8 +236,7 @@ __global__ __launch_bounds__(256) void mha_core_head_kernel(MhaCoreArgs a, int64
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = kt * 16 + 4 * g + r;
-        float sv = acc[kt][r];
-        if (a.scaled) sv = sv / sq;
+        float sv = acc[kt][r] * inv_sq;
         if (mq == 0.f) sv = -1e9f;
         if (key >= S) sv = -INFINITY;
         acc[kt][r] = sv;
@@ -250,7 +249,7 @@ __global__ __launch_bounds__(256) void mha_core_head_kernel(MhaCoreArgs a, int64
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float ev = expf(acc[kt][r] - mx);
+        const float ev = attn_exp(acc[kt][r] - mx);
         acc[kt][r] = ev;
         sum += ev;
       }
@@ -261,11 +260,12 @@ __global__ __launch_bounds__(256) void mha_core_head_kernel(MhaCoreArgs a, int64
       st[0] = mx;
       st[1] = sum;
     }
+    const float inv_sum = 1.f / sum;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float p = acc[kt][r] / sum;
+        float p = acc[kt][r] * inv_sum;
         if (a.dropout_p > 0.f) {
           const int key = kt * 16 + 4 * g + r;
           const uint64_t idx = ((uint64_t)(seq * a.n_heads + hd) * S + (uint64_t)query) * S + (uint64_t)key;
