@@ -18,4 +18,8 @@ for pass in "sq:SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_
   rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $OUT/pmc_$name -- python3 $R/tools/prof_news.py $ARGS > $OUT/pmc_$name.log 2>&1 || { echo "pmc $name failed"; tail -3 $OUT/pmc_$name.log; }
 done
 python3 $R/tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
-cat $OUT/summary.txt
+grep -v "at::native\|rocclr\|^void  " $OUT/summary.txt
+# the same command the bench line comes from, under the kernel tracer
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra > $OUT/bench_trace.log 2>&1 || { echo "bench trace failed"; tail -5 $OUT/bench_trace.log; }
+tail -1 $OUT/bench_trace.log | cut -c1-900
+find $OUT/bench_trace -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c 'head -12 {}' 
