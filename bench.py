@@ -173,6 +173,73 @@ def news_only_extra(device, steps=20, warmup=10):
     return out
 
 
+def other_models_extra(device, steps=5, warmup=2):
+    """BASELINE configs[3]/[4] forward throughput on one GPU: StandardRec (the CL bi-encoder,
+    config/mind_small_CL.yml: additive-only towers + heads) and NAML (title + abstract + category views),
+    B=512 impressions, H=25, C=5, S=50, D=768."""
+    out = {}
+    B, H, C, S, D = 512, 25, 5, 50, 768
+    gen = torch.Generator(device=device)
+    gen.manual_seed(11)
+    for name in ("standard", "NAML"):
+        c = dict(model=name, E=256, bias=False, h=16, D=D, H=H, S=S)
+        model = make_model(Cfg(cases.model_cfg(c)))
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        model.load_state_dict(synth.fill_state_dict(shapes, 99))
+        model = model.eval().to(device)
+
+        def toks(n):
+            x, m = synth.device_tokens(gen, B * n, S, D, device)
+            return x.reshape(B, n, S, D), m.reshape(B, n, S, 1)
+        hist = {"title_emb": toks(H)}
+        cand = {"title_emb": toks(C)}
+        if name == "NAML":
+            hist["abstract_emb"], cand["abstract_emb"] = toks(H), toks(C)
+            for d_, n in ((hist, H), (cand, C)):
+                d_["category_index"] = torch.randint(1, 20, (B, n), generator=gen, device=device, dtype=torch.int32)
+                d_["subcategory_index"] = torch.randint(1, 301, (B, n), generator=gen, device=device, dtype=torch.int32)
+        batch = {"user_features": {"history": hist, "other": {}}, "candidate_features": cand}
+        fn = lambda: model(batch)  # noqa: E731
+        dt = timed(fn, steps, warmup, False) / steps
+        out[name] = dict(impressions_per_s=B / dt, ms=dt * 1e3)
+    return out
+
+
+def train_step_extra(device, steps=5, warmup=2):
+    """The grad step of the reference (training.py:402-431) on the HIP path: NRMS at the shipped
+    config (batch 64, H=25, C=5, S=50, D=768, train-mode attention dropout 0.1), forward + relu/MSE +
+    lambda*InfoNCE on a second history encode + backward + Adam."""
+    w = dict(B=64, H=25, C=5, S=50, D=768, h=16, E=256, A=256)
+    model, _ = build_model(w, device)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    hist, cand = make_inputs(w, device, seed=7)
+    targets = torch.zeros(w["B"], w["C"], 1, device=device)
+    targets[:, 0] = 1.0
+    labels = torch.randint(0, 6, (w["B"],), device=device)
+    batch = {"user_features": {"history": {"title_emb": hist}, "other": {}}, "candidate_features": {"title_emb": cand}}
+
+    def infonce(e, lab, temp=0.08):  # vectorised form of training.py:433-472 (same epsilons)
+        e = torch.nn.functional.normalize(e, dim=-1)
+        sim = (e @ e.mT) / temp
+        eye = torch.eye(e.size(0), dtype=torch.bool, device=e.device)
+        pos = (lab[:, None] == lab[None, :]) & ~eye
+        ex = torch.exp(sim)
+        num = torch.where(pos.any(1), (ex * pos).sum(1), torch.ones_like(ex[:, 0]))
+        li = torch.where(pos.any(1), -torch.log(num / ((ex * ~eye).sum(1) + 1e-12)), torch.zeros_like(num))
+        return li.sum() / (pos.any(1).sum() + 1e-8)
+
+    def fn():
+        opt.zero_grad()
+        preds = torch.relu(model(batch))
+        loss = torch.nn.functional.mse_loss(preds, targets) + 0.1 * infonce(model.get_user_embeddings(batch), labels)
+        loss.backward()
+        opt.step()
+        return loss
+    dt = timed(fn, steps, warmup, False) / steps
+    return dict(ms=dt * 1e3, impressions_per_s=w["B"] / dt, batch=w["B"], loss_finite=bool(torch.isfinite(fn()).item()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -271,6 +338,8 @@ def main():
                 hip.profile_enable(0)
                 out["extra"]["stage_ms_per_step"] = {k: round(v[0], 3) for k, v in st.items()}
                 out["extra"]["stage_tflops"] = {k: (v[2] / (v[0] * 1e-3) / 1e12 if v[0] > 0 else 0.0) for k, v in st.items()}
+                out["extra"]["other_models_fwd_B512_H25"] = other_models_extra(device)
+            out["extra"]["nrms_train_step_B64"] = train_step_extra(device)
         assert torch.isfinite(scores).all()
         print(json.dumps(out))
     if dist_on:
