@@ -252,13 +252,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1
+    # XNRS_BENCH_FORCE_DIST=1 exercises the RCCL init / barrier / MAX-reduce path with a single rank
+    dist_on = world > 1 or os.environ.get("XNRS_BENCH_FORCE_DIST") == "1"
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if dist_on:
-        torch.distributed.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     w = WORKLOAD
     model, sd = build_model(w, device)

@@ -48,10 +48,12 @@ hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t stream);
 
 // ---------------------------------------------------------------- attention core (QK^T, row mask, softmax, PV)
 struct MhaCoreArgs {
-  const float* q;  // element (row, col) at q[row*ld + head*d_k + col]
+  const float* q;  // element (seq, head, s, j) at q[seq*seq_stride + head*head_stride + s*ld + j]
   const float* k;
   const float* v;
   int64_t ld;         // row stride (floats) of q/k/v
+  int64_t seq_stride;   // row-major [rows, 3D] buffer: S*ld ; head-major buffer: n_heads*S*d_k
+  int64_t head_stride;  // row-major: d_k ; head-major: S*d_k
   const float* mask;  // [n_seq*S] fp32 0/1 or null (QUERY-row mask, layers.py:142-144)
   const int32_t* mask_gather_ids;  // nullable: mask row of sequence n is ids[n]
   float* out;         // [n_seq*S, ldo]; head h writes columns [h*d_k, (h+1)*d_k)

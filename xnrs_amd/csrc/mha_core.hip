@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void mha_core_kernel(MhaCoreArgs a, int QT, in
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const float* qrow = a.q + (row0 + (qvalid ? query : 0)) * a.ld + hoff;
+  const int64_t hbase = seq * a.seq_stride + hd * a.head_stride;  // (seq, head) block of q / k / v
+  const float* qrow = a.q + hbase + (int64_t)(qvalid ? query : 0) * a.ld;
   const int nfb = (dk + 15) >> 4;
   for (int fb = 0; fb < nfb; ++fb) {
     const int f0 = fb * 16 + 4 * g;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void mha_core_kernel(MhaCoreArgs a, int QT, in
       const int key = kt * 16 + c;
       f32x4 kf = {0.f, 0.f, 0.f, 0.f};
       if (key < S) {
-        const float* krow = a.k + (row0 + key) * a.ld + hoff;
+        const float* krow = a.k + hbase + (int64_t)key * a.ld;
         if (VEC) {
           if (f0 < dk) kf = *reinterpret_cast<const f32x4*>(krow + f0);
         } else {
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void mha_core_kernel(MhaCoreArgs a, int QT, in
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = kt * 16 + 4 * g + r;
-        vv[r] = (key < S && dv_a < dk) ? a.v[(row0 + key) * a.ld + hoff + dv_a] : 0.f;
+        vv[r] = (key < S && dv_a < dk) ? a.v[hbase + (int64_t)key * a.ld + dv_a] : 0.f;
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[r], acc[kt][r], o, 0, 0, 0);
@@ -184,8 +185,9 @@ __global__ __launch_bounds__(256) void mha_core_head_kernel(MhaCoreArgs a, int64
   const int ld = (int)a.ld;
 
   // ---- K fragments: kf[kt][fb] = K[16kt + c][16fb + 4g .. +3]
-  const float* kbase = a.k + row0 * a.ld + hoff;
-  const float* vbase = a.v + row0 * a.ld + hoff;
+  const int64_t hbase = seq * a.seq_stride + hd * a.head_stride;
+  const float* kbase = a.k + hbase;
+  const float* vbase = a.v + hbase;
   f32x4 kf[KT][NFB];
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256) void mha_core_head_kernel(MhaCoreArgs a, int64
   for (int qt = 0; qt < QT; ++qt) {
     const int query = qt * 16 + c;
     const bool qvalid = query < S;
-    const float* qrow = a.q + (row0 + (qvalid ? query : 0)) * a.ld + hoff;
+    const float* qrow = a.q + hbase + (int64_t)(qvalid ? query : 0) * a.ld;
     f32x4 acc[KT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -305,6 +307,162 @@ static hipError_t launch_head_kt(const MhaCoreArgs& a, hipStream_t stream) {
   }
 }
 
+// LDS-staged path (S <= 64, d_k <= 64): a workgroup serves G = 4/QTP (sequence, head) pairs; the QTP waves of
+// a pair first stage K and V of the head into LDS cooperatively, ALREADY IN MFMA FRAGMENT ORDER (slot
+// ((kt*NFB + fb)*64 + lane) holds exactly the float4 that lane feeds to the MFMAs of key tile kt and
+// feature block fb -- for V the four keys 16kt+4g+r of column 16dt+c, i.e. the transposed gather of the
+// second product), so every fragment read is a linear, conflict-free ds_read_b128 and the padding (keys
+// >= S, features >= d_k) is written as zeros once.  Then each wave owns one 16-query tile.  Compared
+// with the head-per-wave kernel: K/V are loaded once per head by 4x as many lanes, the query tiles run in
+// parallel, and a wave needs ~64 instead of 176 VGPRs (6 instead of 2 waves per SIMD to hide latency).
+template <int KT, int NFB, int QTP>
+__global__ __launch_bounds__(256) void mha_core_lds_kernel(MhaCoreArgs a, int64_t n_pairs) {
+  constexpr int G = 4 / QTP;          // pairs per workgroup
+  constexpr int NTHR = QTP * 64;      // threads per pair
+  constexpr int NSLOT = KT * NFB * 64;
+  __shared__ __attribute__((aligned(16))) f32x4 Ks[G][NSLOT];
+  __shared__ __attribute__((aligned(16))) f32x4 Vs[G][NSLOT];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int gp = tid / NTHR;           // pair slot inside the workgroup
+  const int tp = tid - gp * NTHR;      // thread inside the pair
+  const int qt = tp >> 6;              // this wave's query tile
+  const int64_t pair = (int64_t)blockIdx.x * G + gp;
+  const bool pvalid = pair < n_pairs;
+  const int hd = pvalid ? (int)(pair % a.n_heads) : 0;
+  const int64_t seq = pvalid ? pair / a.n_heads : 0;
+  const int S = a.S, dk = a.d_k;
+  const int64_t row0 = seq * S;
+  const int hoff = hd * dk;
+  const int ld = (int)a.ld;
+  const int64_t hbase = seq * a.seq_stride + hd * a.head_stride;
+  const float* kbase = a.k + hbase;
+  const float* vbase = a.v + hbase;
+
+  if (pvalid) {
+    for (int idx = tp; idx < NSLOT; idx += NTHR) {
+      const int l = idx & 63, blk = idx >> 6;
+      const int kt = blk / NFB, fb = blk - kt * NFB;
+      const int c = l & 15, g = l >> 4;
+      // K fragment: K[16kt + c][16fb + 4g .. +3]
+      const int key = kt * 16 + c, f0 = fb * 16 + 4 * g;
+      f32x4 kv = {0.f, 0.f, 0.f, 0.f};
+      if (key < S && f0 < dk) kv = *reinterpret_cast<const f32x4*>(kbase + key * ld + f0);
+      Ks[gp][idx] = kv;
+      // V fragment: V[16kt + 4g + r][16fb + c], r = 0..3
+      const int dv = fb * 16 + c;
+      f32x4 vv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int vkey = kt * 16 + 4 * g + r;
+        if (vkey < S && dv < dk) vv[r] = vbase[vkey * ld + dv];
+      }
+      Vs[gp][idx] = vv;
+    }
+  }
+  __syncthreads();
+  const int QT = (S + 15) >> 4;
+  if (!pvalid || qt >= QT) return;
+
+  const int c = lane & 15, g = lane >> 4;
+  const int query = qt * 16 + c;
+  const bool qvalid = query < S;
+  const float* qrow = a.q + hbase + (int64_t)(qvalid ? query : 0) * a.ld;
+  f32x4 acc[KT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int fb = 0; fb < NFB; ++fb) {
+    const int f0 = fb * 16 + 4 * g;
+    const f32x4 qf = (qvalid && f0 < dk) ? *reinterpret_cast<const f32x4*>(qrow + f0) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      const f32x4 kf = Ks[gp][(kt * NFB + fb) * 64 + lane];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qf[e], acc[kt], 0, 0, 0);
+    }
+  }
+  const int64_t mrow = a.mask ? (a.mask_gather_ids ? (int64_t)a.mask_gather_ids[seq] * S : row0) : 0;
+  const float mq = (a.mask && qvalid) ? a.mask[mrow + query] : 1.f;
+  const float inv_sq = a.scaled ? 1.f / sqrtf((float)dk) : 1.f;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kt * 16 + 4 * g + r;
+      float sv = acc[kt][r] * inv_sq;
+      if (mq == 0.f) sv = -1e9f;
+      if (key >= S) sv = -INFINITY;
+      acc[kt][r] = sv;
+      mx = fmaxf(mx, sv);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ev = attn_exp(acc[kt][r] - mx);
+      acc[kt][r] = ev;
+      sum += ev;
+    }
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  if (a.stats && qvalid && g == 0) {
+    float* st = a.stats + ((seq * a.n_heads + hd) * (int64_t)S + query) * 2;
+    st[0] = mx;
+    st[1] = sum;
+  }
+  const float inv_sum = 1.f / sum;
+  const float keep = 1.f - a.dropout_p;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float p = acc[kt][r] * inv_sum;
+      if (a.dropout_p > 0.f) {
+        const int key = kt * 16 + 4 * g + r;
+        const uint64_t idx = ((uint64_t)(seq * a.n_heads + hd) * S + (uint64_t)query) * S + (uint64_t)key;
+        p = (uniform01(a.seed, idx) < keep) ? p / keep : 0.f;
+      }
+      acc[kt][r] = p;
+    }
+#pragma unroll
+  for (int dt = 0; dt < NFB; ++dt) {
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      const f32x4 vf = Vs[gp][(kt * NFB + dt) * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r], acc[kt][r], o, 0, 0, 0);
+    }
+    const int dv0 = dt * 16 + 4 * g;
+    if (qvalid && dv0 < dk) *reinterpret_cast<f32x4*>(a.out + (row0 + query) * a.ldo + hoff + dv0) = o;
+  }
+}
+
+template <int KT, int NFB, int QTP>
+static hipError_t launch_lds(const MhaCoreArgs& a, hipStream_t stream) {
+  constexpr int G = 4 / QTP;
+  const int64_t n_pairs = a.n_seq * a.n_heads;
+  const int64_t grid = (n_pairs + G - 1) / G;
+  if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((mha_core_lds_kernel<KT, NFB, QTP>), dim3((unsigned)grid), dim3(256), 0, stream, a, n_pairs);
+  return hipGetLastError();
+}
+
+template <int KT, int QTP>
+static hipError_t launch_lds_kt(const MhaCoreArgs& a, hipStream_t stream) {
+  switch ((a.d_k + 15) / 16) {
+    case 1: return launch_lds<KT, 1, QTP>(a, stream);
+    case 2: return launch_lds<KT, 2, QTP>(a, stream);
+    case 3: return launch_lds<KT, 3, QTP>(a, stream);
+    default: return launch_lds<KT, 4, QTP>(a, stream);
+  }
+}
+
 template <int KT>
 static hipError_t launch_kt(const MhaCoreArgs& a, bool vec, hipStream_t stream) {
   const int QT = (a.S + 15) / 16;
@@ -326,7 +484,19 @@ hipError_t launch_mha_core(const MhaCoreArgs& a, hipStream_t stream) {
                    ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0);
   const int KT = (a.S + 15) / 16;
   const char* fe = getenv("XNRS_MHA_HEADWAVE");  // development knob for A/B runs; default on
-  const bool fast = vec && a.S <= 64 && a.d_k <= 64 && ((int64_t)a.n_seq * a.S * a.ld < (1ll << 31)) && !(fe && fe[0] == '0');
+  const bool fast = vec && a.S <= 64 && a.d_k <= 64 && ((int64_t)a.S * a.ld < (1ll << 31)) && !(fe && fe[0] == '0');
+  // three or four query tiles: LDS-staged kernel (one wave per tile, K/V shared through LDS; 0.99 vs 1.06 ms
+  // at S=50); one or two tiles: head-per-wave kernel (0.17 vs 0.21 ms at S=30).  XNRS_MHA_LDS=0|1 forces one.
+  const char* le = getenv("XNRS_MHA_LDS");
+  const bool use_lds = le ? (le[0] != '0') : (KT >= 3);
+  if (fast && use_lds) {
+    switch (KT) {
+      case 1: return launch_lds_kt<1, 1>(a, stream);
+      case 2: return launch_lds_kt<2, 2>(a, stream);
+      case 3: return launch_lds_kt<3, 4>(a, stream);
+      default: return launch_lds_kt<4, 4>(a, stream);
+    }
+  }
   if (fast) {
     switch (KT) {
       case 1: return launch_head_kt<1>(a, stream);
