@@ -180,6 +180,35 @@ int32_t xnrs_embedding_linear_bwd(const float *table, const int32_t *ids, const 
 int32_t xnrs_dot_scoring_bwd(const float *u, const float *c, const float *dr, float *du, float *dc, int64_t B,
                              int32_t C, int32_t E, void *stream);
 
+/* ---- device-side batch assembly and evaluation -----------------------
+ * Click histories / positives / negatives live on the device as CSR arrays of ROWS into the resident news
+ * table ([n_rows,S,D] + mask; `pad_row` = the empty slot: all-zero tokens and mask, dataset.py:82-85).
+ *
+ * xnrs_assemble_train_batch: NewsRecDataset.__getitem__ 'train' mode + custom_collate_fn
+ *   (xnrs/data/dataset.py:54-57,77-85,97-109,147; xnrs/utils.py:190-204) -> hist_rows:(B,l_hist) (the LAST
+ *   l_hist clicks, padding behind), cand_rows:(B,1+n_neg) (one random positive, n_neg negatives drawn WITH
+ *   replacement); targets are the constant [1,0,..].  Draws: splitmix64(seed, session, slot) % n -- a
+ *   counter-based stream (Python's `random` cannot be matched), restated bit for bit by the oracle.
+ * xnrs_assemble_eval_batch: 'eval' mode (dataset.py:58-61,149): all positives then all negatives;
+ *   cand_off:(B+1) is supplied by the caller (prefix sum of the per-session counts).
+ * xnrs_score_csr: r[e] = <vecs[cand_rows[e]], u[cand_sess[e]]> (+ReLU, training.py:392) against news
+ *   vectors pre-encoded once per epoch (scoring.py:23 per impression, training.py:194-203).
+ * xnrs_rank_metrics: xnrs/evaluation/metrics.py:9-64 per impression after np.nan_to_num
+ *   (training.py:210-211); out:(B,9) = ndcg@5, ndcg@10, rr, ctr@1, ctr@10, auc, acc, rec, prec.
+ *   Ties in the ranking are broken "higher original index first". */
+int32_t xnrs_assemble_train_batch(const int64_t *sess, int64_t B, const int64_t *hist_off, const int32_t *hist_val,
+                                  const int64_t *pos_off, const int32_t *pos_val, const int64_t *neg_off,
+                                  const int32_t *neg_val, int32_t l_hist, int32_t n_neg, int32_t pad_row, uint64_t seed,
+                                  int32_t *hist_rows, int32_t *cand_rows, void *stream);
+int32_t xnrs_assemble_eval_batch(const int64_t *sess, int64_t B, const int64_t *hist_off, const int32_t *hist_val,
+                                 const int64_t *pos_off, const int32_t *pos_val, const int64_t *neg_off,
+                                 const int32_t *neg_val, int32_t l_hist, int32_t pad_row, const int64_t *cand_off,
+                                 int32_t *hist_rows, int32_t *cand_rows, int32_t *cand_sess, float *targets, void *stream);
+int32_t xnrs_score_csr(const float *vecs, const int32_t *cand_rows, const int32_t *cand_sess, const float *u, float *r,
+                       int64_t n_cand, int32_t E, int32_t relu, void *stream);
+int32_t xnrs_rank_metrics(const float *scores, const float *targets, const int64_t *cand_off, float *out, int64_t B,
+                          void *stream);
+
 /* ---- measurement aid (no reference counterpart) ----------------------------------------------
  * When enabled, the sequence-encoder pipeline brackets each kernel launch of the selected stages
  * with hipEvents on the caller's stream (the only process-global state in the library; off by

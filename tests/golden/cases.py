@@ -136,3 +136,37 @@ def infonce_inputs():
     e = torch.from_numpy(rng.standard_normal((8, 16)).astype(np.float32))
     lab = torch.from_numpy(rng.integers(0, 3, size=(8,)))
     return e, lab
+
+
+# ----------------------------------------------------------------------------------------------
+# data-side cases (device batch assembly / evaluation): a tiny synthetic corpus in the reference's
+# in-memory formats (mind.py:161-164 news dict; dataset.py:50-51 sessions)
+DATA = dict(n_news=20, S=4, D=8, l_hist=5, n_neg=4, seed=600)
+
+
+def data_corpus(c=None):
+    from xnrs_amd import synth
+    c = c or DATA
+    rng = synth.rng_for(c["seed"])
+    news_feat = {}
+    for i in range(c["n_news"]):
+        L = int(rng.integers(1, c["S"] + 1))
+        emb = rng.standard_normal((1, c["S"], c["D"])).astype(np.float32)
+        mask = (np.arange(c["S"])[None, :] < L).astype(np.float32)
+        news_feat[f"N{i}"] = {"title_emb": (emb, mask), "category_index": int(rng.integers(1, 6))}
+    ids = list(news_feat)
+    sessions = []
+    for s_i, (nh, npos, nneg) in enumerate([(2, 1, 3), (5, 2, 4), (9, 1, 9), (1, 3, 2), (7, 1, 12), (4, 2, 6)]):
+        pick = lambda k: [ids[int(j)] for j in rng.integers(0, len(ids), size=k)]  # noqa: E731
+        sessions.append({"history": pick(nh), "positives": pick(npos), "negatives": pick(nneg),
+                         "main_theme": f"theme{s_i % 3}", "main_category": "news", "user_index": s_i})
+    return news_feat, sessions
+
+
+METRIC_CASES = {
+    "plain": ([1, 0, 0, 1, 0, 0, 0], [0.9, 0.1, 0.5, 0.4, 0.45, 0.0, 0.3]),
+    "relu_ties": ([1, 0, 0, 0, 1, 0], [0.7, 0.0, 0.0, 0.2, 0.0, 0.0]),
+    "one_pos_last": ([0, 0, 0, 0, 1], [0.5, 0.4, 0.3, 0.2, 0.1]),
+    "over_one": ([1, 0, 1, 0], [1.7, 0.6, 0.2, 0.49]),
+    "twelve": ([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 1], [0.31, 0.9, 0.12, 0.5, 0.77, 0.62, 0.05, 0.41, 0.8, 0.33, 0.2, 0.1]),
+}

@@ -186,6 +186,46 @@ def grad_cases():
     return out
 
 
+def data_cases():
+    """Outputs of the REAL NewsRecDataset / custom_collate_fn / evaluation.metrics on the tiny corpus."""
+    import random
+    from xnrs.data.dataset import NewsRecDataset
+    from xnrs.utils import custom_collate_fn
+    from xnrs.evaluation import metrics as M
+    c = cases.DATA
+    news_feat, sessions = cases.data_corpus(c)
+    out = {}
+    kw = dict(l_seq=c["S"], l_hist=c["l_hist"], text_features=["title_emb"], catg_features=["category_index"])
+    ev = NewsRecDataset(uds=sessions, news_feat=news_feat, mode="eval", n_negatives=None, **kw)
+    for i in range(len(sessions)):
+        it = ev[i]
+        hx, hm = it["user_features"]["history"]["title_emb"]
+        cx, cm = it["candidate_features"]["title_emb"]
+        out[f"data/eval{i}/hx"], out[f"data/eval{i}/hm"] = npy(hx), npy(hm)
+        out[f"data/eval{i}/cx"], out[f"data/eval{i}/cm"] = npy(cx), npy(cm)
+        out[f"data/eval{i}/t"] = npy(it["targets"])
+        out[f"data/eval{i}/hcat"] = npy(it["user_features"]["history"]["category_index"])
+        out[f"data/eval{i}/ccat"] = npy(it["candidate_features"]["category_index"])
+    tr = NewsRecDataset(uds=sessions, news_feat=news_feat, mode="train", n_negatives=c["n_neg"], **kw)
+    random.seed(1234)
+    items = [tr[i] for i in range(len(sessions))]
+    chosen = [it["item_ids"] for it in items]
+    batch = custom_collate_fn(items)
+    bx, bm = batch["user_features"]["history"]["title_emb"]
+    cx, cm = batch["candidate_features"]["title_emb"]
+    out["data/train/hx"], out["data/train/hm"] = npy(bx), npy(bm)
+    out["data/train/cx"], out["data/train/cm"] = npy(cx), npy(cm)
+    out["data/train/t"] = npy(batch["targets"])
+    ids = list(news_feat)
+    out["data/train/chosen"] = np.array([[ids.index(n) for n in ch] for ch in chosen], dtype=np.int32)
+    for name, (t, s_) in cases.METRIC_CASES.items():
+        t, s_ = np.array(t, dtype=np.float64), np.array(s_, dtype=np.float64)
+        out[f"metrics/{name}"] = np.array([M.ndcg_score(t, s_, k=5), M.ndcg_score(t, s_, k=10), M.rr_score(t, s_),
+                                           M.ctr_score(t, s_, k=1), M.ctr_score(t, s_, k=10), M.auc_score(t, s_),
+                                           M.acc_score(t, s_), M.recall_score(t, s_), M.precision_score(t, s_)])
+    return out
+
+
 def error_cases():
     """Pin the reference's D % h != 0 failure (layers.py:111,133)."""
     mod = layers.MultiHeadAttention(16, 300)
@@ -205,6 +245,7 @@ def main():
         "models": model_cases(),
         "lstur": lstur_case(),
         "grads": grad_cases(),
+        "data": data_cases(),
     }
     for g, d in groups.items():
         np.savez_compressed(os.path.join(HERE, f"{g}.npz"), **d)

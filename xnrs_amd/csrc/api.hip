@@ -718,3 +718,51 @@ int32_t xnrs_dot_scoring_bwd(const float* u, const float* c, const float* dr, fl
 }
 
 }  // extern "C"
+
+extern "C" {
+
+int32_t xnrs_assemble_train_batch(const int64_t* sess, int64_t B, const int64_t* hist_off, const int32_t* hist_val,
+                                  const int64_t* pos_off, const int32_t* pos_val, const int64_t* neg_off,
+                                  const int32_t* neg_val, int32_t l_hist, int32_t n_neg, int32_t pad_row, uint64_t seed,
+                                  int32_t* hist_rows, int32_t* cand_rows, void* stream) {
+  if (B == 0) return XNRS_OK;
+  if (!sess || !hist_off || !pos_off || !neg_off || !hist_rows || !cand_rows || B < 0 || l_hist <= 0 || n_neg < 0)
+    return XNRS_EINVAL;
+  BatchArgs a{};
+  a.sess = sess; a.hist_off = hist_off; a.hist_val = hist_val; a.pos_off = pos_off; a.pos_val = pos_val;
+  a.neg_off = neg_off; a.neg_val = neg_val; a.B = B; a.l_hist = l_hist; a.n_neg = n_neg; a.pad_row = pad_row;
+  a.seed = seed; a.hist_out = hist_rows; a.cand_out = cand_rows;
+  return hip_rc(launch_assemble_train(a, (hipStream_t)stream));
+}
+
+int32_t xnrs_assemble_eval_batch(const int64_t* sess, int64_t B, const int64_t* hist_off, const int32_t* hist_val,
+                                 const int64_t* pos_off, const int32_t* pos_val, const int64_t* neg_off,
+                                 const int32_t* neg_val, int32_t l_hist, int32_t pad_row, const int64_t* cand_off,
+                                 int32_t* hist_rows, int32_t* cand_rows, int32_t* cand_sess, float* targets, void* stream) {
+  if (B == 0) return XNRS_OK;
+  if (!sess || !hist_off || !pos_off || !neg_off || !cand_off || !hist_rows || !cand_rows || !cand_sess || !targets ||
+      B < 0 || l_hist <= 0)
+    return XNRS_EINVAL;
+  BatchArgs a{};
+  a.sess = sess; a.hist_off = hist_off; a.hist_val = hist_val; a.pos_off = pos_off; a.pos_val = pos_val;
+  a.neg_off = neg_off; a.neg_val = neg_val; a.B = B; a.l_hist = l_hist; a.pad_row = pad_row;
+  a.hist_out = hist_rows; a.cand_out = cand_rows; a.cand_off_out = cand_off; a.cand_sess_out = cand_sess;
+  a.targets_out = targets;
+  return hip_rc(launch_assemble_eval(a, (hipStream_t)stream));
+}
+
+int32_t xnrs_score_csr(const float* vecs, const int32_t* cand_rows, const int32_t* cand_sess, const float* u, float* r,
+                       int64_t n_cand, int32_t E, int32_t relu, void* stream) {
+  if (n_cand == 0) return XNRS_OK;
+  if (!vecs || !cand_rows || !cand_sess || !u || !r || n_cand < 0 || E <= 0) return XNRS_EINVAL;
+  return hip_rc(launch_score_csr(vecs, cand_rows, cand_sess, u, r, n_cand, E, relu, (hipStream_t)stream));
+}
+
+int32_t xnrs_rank_metrics(const float* scores, const float* targets, const int64_t* cand_off, float* out, int64_t B,
+                          void* stream) {
+  if (B == 0) return XNRS_OK;
+  if (!scores || !targets || !cand_off || !out || B < 0) return XNRS_EINVAL;
+  return hip_rc(launch_rank_metrics(scores, targets, cand_off, out, B, (hipStream_t)stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,191 @@
+// Device-side batch assembly and evaluation kernels -- the callers / data formats on either side of the
+// encoders.  Integer / index work, HBM-bound, no MFMA.
+//
+//   assemble_train : NewsRecDataset.__getitem__ in 'train' mode (xnrs/data/dataset.py:54-57,77-85,97-109,147)
+//                    + custom_collate_fn (xnrs/utils.py:190-204), producing ROW IDS into the device-resident
+//                    news table instead of 4.6 MB of gathered token tensors per impression.
+//   assemble_eval  : the same in 'eval' mode (dataset.py:58-61,149): all positives then all negatives,
+//                    variable C -> CSR.
+//   score_csr      : DotScoring over a CSR candidate list against pre-encoded news vectors
+//                    (scoring.py:23 applied per impression, training.py:194-203 with batch_size 1).
+//   rank_metrics   : xnrs/evaluation/metrics.py:9-64 per impression (nDCG@k, RR, CTR@k, AUC, acc/rec/prec).
+#include "kernels.h"
+
+namespace xnrs {
+
+__device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t a, uint64_t b) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (a * 0x100000001B3ull + b + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// one thread per output id
+__global__ __launch_bounds__(256) void assemble_train_kernel(BatchArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int W = a.l_hist + 1 + a.n_neg;
+  if (i >= a.B * W) return;
+  const int64_t b = i / W;
+  const int j = (int)(i - b * W);
+  const int64_t s = a.sess[b];
+  if (j < a.l_hist) {
+    // the LAST l_hist clicked news first, zero padding behind them (dataset.py:77-85)
+    const int64_t lo = a.hist_off[s], hi = a.hist_off[s + 1];
+    const int64_t n = (hi - lo < a.l_hist) ? (hi - lo) : a.l_hist;
+    a.hist_out[b * a.l_hist + j] = (j < n) ? a.hist_val[hi - n + j] : a.pad_row;
+  } else {
+    const int c = j - a.l_hist;  // 0 = the positive, 1.. = negatives
+    int32_t row = a.pad_row;
+    if (c == 0) {
+      const int64_t lo = a.pos_off[s], n = a.pos_off[s + 1] - lo;
+      if (n > 0) row = a.pos_val[lo + (int64_t)(mix64(a.seed, (uint64_t)s, 0) % (uint64_t)n)];  // random.choice
+    } else {
+      const int64_t lo = a.neg_off[s], n = a.neg_off[s + 1] - lo;
+      if (n > 0) row = a.neg_val[lo + (int64_t)(mix64(a.seed, (uint64_t)s, (uint64_t)c) % (uint64_t)n)];  // random.choices (with replacement)
+    }
+    a.cand_out[b * (1 + a.n_neg) + c] = row;
+  }
+}
+
+hipError_t launch_assemble_train(const BatchArgs& a, hipStream_t stream) {
+  const int64_t n = a.B * (a.l_hist + 1 + a.n_neg);
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(assemble_train_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+// one wave per impression: history ids + candidate CSR fill (offsets computed by the caller)
+__global__ __launch_bounds__(256) void assemble_eval_kernel(BatchArgs a) {
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.B) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t s = a.sess[b];
+  {
+    const int64_t lo = a.hist_off[s], hi = a.hist_off[s + 1];
+    const int64_t n = (hi - lo < a.l_hist) ? (hi - lo) : a.l_hist;
+    for (int j = lane; j < a.l_hist; j += 64) a.hist_out[b * a.l_hist + j] = (j < n) ? a.hist_val[hi - n + j] : a.pad_row;
+  }
+  const int64_t plo = a.pos_off[s], np = a.pos_off[s + 1] - plo;
+  const int64_t nlo = a.neg_off[s], nn = a.neg_off[s + 1] - nlo;
+  const int64_t o = a.cand_off_out[b];
+  for (int64_t k = lane; k < np + nn; k += 64) {
+    a.cand_out[o + k] = (k < np) ? a.pos_val[plo + k] : a.neg_val[nlo + (k - np)];
+    a.cand_sess_out[o + k] = (int32_t)b;
+    a.targets_out[o + k] = (k < np) ? 1.f : 0.f;
+  }
+}
+
+hipError_t launch_assemble_eval(const BatchArgs& a, hipStream_t stream) {
+  if (a.B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(assemble_eval_kernel, dim3((unsigned)((a.B + 3) / 4)), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+// r[e] = <vecs[cand_rows[e], :], u[cand_sess[e], :]> : one wave per candidate entry
+__global__ __launch_bounds__(256) void score_csr_kernel(const float* vecs, const int32_t* rows, const int32_t* sess, const float* u,
+                                                         float* r, int64_t n, int E, int relu) {
+  const int64_t e = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= n) return;
+  const int lane = threadIdx.x & 63;
+  const float* v = vecs + (int64_t)rows[e] * E;
+  const float* uu = u + (int64_t)sess[e] * E;
+  float acc = 0.f;
+  for (int k = lane; k < E; k += 64) acc = fmaf(v[k], uu[k], acc);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) r[e] = relu ? fmaxf(acc, 0.f) : acc;
+}
+
+hipError_t launch_score_csr(const float* vecs, const int32_t* rows, const int32_t* sess, const float* u, float* r, int64_t n,
+                            int E, int relu, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(score_csr_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, vecs, rows, sess, u, r, n, E, relu);
+  return hipGetLastError();
+}
+
+// Per-impression ranking metrics, one wave per impression, O(C^2) rank counting (C is tens to hundreds).
+// Order = np.argsort(score)[::-1]; ties are broken "higher original index first" (what a stable ascending
+// sort reversed gives; numpy's default sort is stable below 17 elements -- beyond that the reference's own
+// tie order is unspecified).  out[b, :] = {ndcg@5, ndcg@10, rr, ctr@1, ctr@10, auc, acc, rec, prec}.
+__global__ __launch_bounds__(256) void rank_metrics_kernel(const float* score, const float* target, const int64_t* off, float* out,
+                                                            int64_t B) {
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t lo = off[b];
+  const int C = (int)(off[b + 1] - lo);
+  const float* s = score + lo;
+  const float* t = target + lo;
+  float dcg5 = 0.f, dcg10 = 0.f, rr = 0.f, top1 = 0.f, top10 = 0.f, npos = 0.f, conc = 0.f;
+  float tp = 0.f, fp = 0.f, fn = 0.f, tn = 0.f;
+  for (int e = lane; e < C; e += 64) {
+    float se = s[e];
+    if (se != se) se = 0.f;  // np.nan_to_num(nan=0, posinf=1, neginf=0) (training.py:210-211)
+    else if (se == INFINITY) se = 1.f;
+    else if (se == -INFINITY) se = 0.f;
+    const float te = t[e];
+    int rank = 1;
+    float gt = 0.f, eq = 0.f;  // negatives scored below / equal (for AUC), only used when te == 1
+    for (int f = 0; f < C; ++f) {
+      float sf = s[f];
+      if (sf != sf) sf = 0.f;
+      else if (sf == INFINITY) sf = 1.f;
+      else if (sf == -INFINITY) sf = 0.f;
+      if (sf > se || (sf == se && f > e)) ++rank;
+      if (t[f] == 0.f) {
+        if (sf < se) gt += 1.f;
+        else if (sf == se) eq += 1.f;
+      }
+    }
+    const float gain = exp2f(te) - 1.f;  // 2**y - 1 (metrics.py:12)
+    const float disc = log2f((float)rank + 1.f);
+    if (rank <= 5) dcg5 += gain / disc;
+    if (rank <= 10) dcg10 += gain / disc;
+    if (te > 0.f) {
+      rr = fmaxf(rr, te / (float)rank);
+      conc += gt + 0.5f * eq;
+      npos += 1.f;
+    }
+    if (rank <= 1) top1 += te;
+    if (rank <= 10) top10 += te;
+    const float pred = rintf(fminf(fmaxf(se, 0.f), 1.f));  // np.round(np.clip(s, 0, 1)): round-half-even
+    if (pred > 0.5f) { if (te > 0.5f) tp += 1.f; else fp += 1.f; }
+    else { if (te > 0.5f) fn += 1.f; else tn += 1.f; }
+  }
+  float v[11] = {dcg5, dcg10, top1, top10, npos, conc, tp, fp, fn, tn, 0.f};
+#pragma unroll
+  for (int i = 0; i < 10; ++i)
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) v[i] += __shfl_xor(v[i], o2);
+#pragma unroll
+  for (int o2 = 32; o2 > 0; o2 >>= 1) rr = fmaxf(rr, __shfl_xor(rr, o2));
+  if (lane == 0) {
+    const float np_ = v[4], nneg = (float)C - v[4];
+    // ideal DCG: the positives first (metrics.py:18-19: dcg_score(y_true, y_true, k))
+    float best5 = 0.f, best10 = 0.f;
+    for (int i = 0; i < 10 && i < (int)np_; ++i) {
+      const float d = 1.f / log2f((float)i + 2.f);
+      if (i < 5) best5 += d;
+      best10 += d;
+    }
+    float* o = out + b * 9;
+    o[0] = v[0] / best5;
+    o[1] = v[1] / best10;
+    o[2] = rr;
+    o[3] = v[2] / (float)(C < 1 ? C : 1);
+    o[4] = v[3] / (float)(C < 10 ? C : 10);
+    o[5] = v[5] / (np_ * nneg);
+    o[6] = (v[6] + v[9]) / (float)C;
+    o[7] = v[6] / (v[6] + v[8]);
+    o[8] = (v[6] + v[7]) > 0.f ? v[6] / (v[6] + v[7]) : 0.f;  // zero_division=0 (metrics.py:58)
+  }
+}
+
+hipError_t launch_rank_metrics(const float* score, const float* target, const int64_t* off, float* out, int64_t B,
+                               hipStream_t stream) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(rank_metrics_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, score, target, off, out, B);
+  return hipGetLastError();
+}
+
+}  // namespace xnrs

@@ -177,4 +177,30 @@ hipError_t launch_collapse_mask(const float* m, const int32_t* gather_ids, float
 hipError_t launch_dot_scoring(const float* u, const float* c, float* r, int64_t B, int32_t C, int32_t E,
                               int32_t normalize, hipStream_t stream);
 
+// ---------------------------------------------------------------- device-side batch assembly / evaluation
+struct BatchArgs {
+  const int64_t* sess;       // [B] session (impression) indices
+  const int64_t* hist_off;   // CSR offsets [n_sess+1] and values (table rows) of the click histories
+  const int32_t* hist_val;
+  const int64_t* pos_off;
+  const int32_t* pos_val;
+  const int64_t* neg_off;
+  const int32_t* neg_val;
+  int64_t B;
+  int32_t l_hist, n_neg;
+  int32_t pad_row;           // table row of the empty slot (all-zero tokens and mask)
+  uint64_t seed;
+  int32_t* hist_out;         // [B, l_hist]
+  int32_t* cand_out;         // train: [B, 1+n_neg]; eval: CSR values
+  const int64_t* cand_off_out;  // eval: [B+1] offsets (given)
+  int32_t* cand_sess_out;    // eval: [n_cand] impression index of every candidate
+  float* targets_out;        // eval: [n_cand]
+};
+hipError_t launch_assemble_train(const BatchArgs& a, hipStream_t stream);
+hipError_t launch_assemble_eval(const BatchArgs& a, hipStream_t stream);
+hipError_t launch_score_csr(const float* vecs, const int32_t* rows, const int32_t* sess, const float* u, float* r, int64_t n,
+                            int E, int relu, hipStream_t stream);
+hipError_t launch_rank_metrics(const float* score, const float* target, const int64_t* off, float* out, int64_t B,
+                               hipStream_t stream);
+
 }  // namespace xnrs

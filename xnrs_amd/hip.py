@@ -27,6 +27,7 @@ SYMBOLS = (
     "xnrs_seq_encoder_saved_bytes", "xnrs_seq_encoder_fwd_train", "xnrs_seq_encoder_bwd_workspace_bytes",
     "xnrs_seq_encoder_bwd", "xnrs_linear_bwd_workspace_bytes", "xnrs_linear_bwd",
     "xnrs_embedding_linear_bwd_workspace_bytes", "xnrs_embedding_linear_bwd", "xnrs_dot_scoring_bwd",
+    "xnrs_assemble_train_batch", "xnrs_assemble_eval_batch", "xnrs_score_csr", "xnrs_rank_metrics",
 )
 POOL_NONE = -1
 PROFILE_STAGES = ("qkv_gemm", "attention_core", "out_gemm", "fc1_tanh_gemm", "pool", "head_gemms")
@@ -126,6 +127,14 @@ def lib():
     l.xnrs_embedding_linear_bwd.argtypes = [p, p, p, p, p, p, p, i64, i32, i32, i32, p, sz, p]
     l.xnrs_dot_scoring_bwd.restype = i32
     l.xnrs_dot_scoring_bwd.argtypes = [p, p, p, p, p, i64, i32, i32, p]
+    l.xnrs_assemble_train_batch.restype = i32
+    l.xnrs_assemble_train_batch.argtypes = [p, i64, p, p, p, p, p, p, i32, i32, i32, C.c_uint64, p, p, p]
+    l.xnrs_assemble_eval_batch.restype = i32
+    l.xnrs_assemble_eval_batch.argtypes = [p, i64, p, p, p, p, p, p, i32, i32, p, p, p, p, p, p]
+    l.xnrs_score_csr.restype = i32
+    l.xnrs_score_csr.argtypes = [p, p, p, p, p, i64, i32, i32, p]
+    l.xnrs_rank_metrics.restype = i32
+    l.xnrs_rank_metrics.argtypes = [p, p, p, p, i64, p]
     l.xnrs_profile_enable.restype = i32
     l.xnrs_profile_enable.argtypes = [C.c_uint32]
     l.xnrs_profile_read.restype = i32
