@@ -219,20 +219,12 @@ def train_step_extra(device, steps=5, warmup=2):
     labels = torch.randint(0, 6, (w["B"],), device=device)
     batch = {"user_features": {"history": {"title_emb": hist}, "other": {}}, "candidate_features": {"title_emb": cand}}
 
-    def infonce(e, lab, temp=0.08):  # vectorised form of training.py:433-472 (same epsilons)
-        e = torch.nn.functional.normalize(e, dim=-1)
-        sim = (e @ e.mT) / temp
-        eye = torch.eye(e.size(0), dtype=torch.bool, device=e.device)
-        pos = (lab[:, None] == lab[None, :]) & ~eye
-        ex = torch.exp(sim)
-        num = torch.where(pos.any(1), (ex * pos).sum(1), torch.ones_like(ex[:, 0]))
-        li = torch.where(pos.any(1), -torch.log(num / ((ex * ~eye).sum(1) + 1e-12)), torch.zeros_like(num))
-        return li.sum() / (pos.any(1).sum() + 1e-8)
+    from xnrs_amd.losses import contrastive_loss as infonce  # fused HIP forward/backward (training.py:433-472)
 
     def fn():
         opt.zero_grad()
         preds = torch.relu(model(batch))
-        loss = torch.nn.functional.mse_loss(preds, targets) + 0.1 * infonce(model.get_user_embeddings(batch), labels)
+        loss = torch.nn.functional.mse_loss(preds, targets) + 0.1 * infonce(model.get_user_embeddings(batch), labels, 0.08)
         loss.backward()
         opt.step()
         return loss

@@ -209,6 +209,17 @@ int32_t xnrs_score_csr(const float *vecs, const int32_t *cand_rows, const int32_
 int32_t xnrs_rank_metrics(const float *scores, const float *targets, const int64_t *cand_off, float *out, int64_t B,
                           void *stream);
 
+/* ---- in-batch InfoNCE (ContrastiveRankingTrainer._compute_contrastive_loss, training.py:433-472) ----
+ * emb:(B,E) user embeddings, labels:(B) int64 -> loss:(1).  Same epsilons as the reference: F.normalize
+ * eps 1e-12, denominator + 1e-12, mean over rows with >= 1 positive / (count + 1e-8).  `saved`
+ * (xnrs_infonce_saved_bytes) carries the normalised embeddings and row sums to the backward, which returns
+ * d loss / d emb scaled by the upstream scalar gradient *gout (device pointer).  E <= 1024. */
+size_t xnrs_infonce_saved_bytes(int64_t B, int32_t E);
+int32_t xnrs_infonce_fwd(const float *emb, const int64_t *labels, int64_t B, int32_t E, float temperature, float *loss,
+                         void *saved, size_t saved_bytes, void *stream);
+int32_t xnrs_infonce_bwd(const int64_t *labels, int64_t B, int32_t E, float temperature, const void *saved,
+                         size_t saved_bytes, const float *gout, float *demb, void *stream);
+
 /* ---- measurement aid (no reference counterpart) ----------------------------------------------
  * When enabled, the sequence-encoder pipeline brackets each kernel launch of the selected stages
  * with hipEvents on the caller's stream (the only process-global state in the library; off by

@@ -205,3 +205,37 @@ def test_user_encoder_return_weights_grad():
     H.assert_close(a, ao)
     H.assert_close(xd.grad, xo.grad, GTOL)
     check_param_grads(enc, osd)
+
+
+def test_fused_infonce_matches_reference_golden_and_oracle():
+    """xnrs_amd.losses.contrastive_loss == the REAL reference's _compute_contrastive_loss (golden) and the
+    oracle, value and gradient; rows without a positive are skipped; no-positive batches give 0."""
+    from xnrs_amd.losses import contrastive_loss
+    g = H.golden("grads")
+    e, lab = cases.infonce_inputs()
+    ed = e.to(DEV).requires_grad_(True)
+    l = contrastive_loss(ed, lab.to(DEV), 0.08)
+    l.backward()
+    H.assert_close(l, g["infonce/loss"], 2e-6)
+    H.assert_close(ed.grad, g["infonce/grad"], 2e-5)
+    rng = synth.rng_for(71)
+    for B, E, nlab in ((64, 256, 6), (33, 48, 40), (16, 1024, 2), (5, 16, 5)):
+        x = torch.from_numpy(rng.standard_normal((B, E)).astype("float32") * 0.3)
+        lab = torch.from_numpy(rng.integers(0, nlab, size=(B,)))
+        if B == 5:
+            lab = torch.arange(5)  # all unique: count == 0 -> loss 0 / 1e-8 = 0
+        xd = x.to(DEV).requires_grad_(True)
+        ld = contrastive_loss(xd, lab.to(DEV), 0.08)
+        (ld * 1.7).backward()
+        xo = x.clone().requires_grad_(True)
+        lo = O.contrastive_loss(xo, lab, 0.08)
+        (lo * 1.7).backward()
+        H.assert_close(ld, lo, 2e-5, f"loss B={B}") if lo.abs() > 0 else None
+        if lo.abs() == 0:
+            assert ld.item() == 0.0 and xd.grad.abs().max().item() == 0.0
+        else:
+            H.assert_close(xd.grad, xo.grad, 1e-4, f"grad B={B}")
+    # NAML hands (B,1,E) (naml.py:146-147)
+    x3 = torch.randn(8, 1, 16, device=DEV)
+    lab = torch.tensor([0, 1, 0, 1, 2, 2, 0, 1], device=DEV)
+    assert torch.equal(contrastive_loss(x3, lab, 0.08), contrastive_loss(x3[:, 0], lab, 0.08))

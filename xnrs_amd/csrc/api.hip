@@ -766,3 +766,23 @@ int32_t xnrs_rank_metrics(const float* scores, const float* targets, const int64
 }
 
 }  // extern "C"
+
+extern "C" {
+
+size_t xnrs_infonce_saved_bytes(int64_t B, int32_t E) { return ((size_t)B * E + 4 * (size_t)B + 1) * sizeof(float); }
+
+int32_t xnrs_infonce_fwd(const float* emb, const int64_t* labels, int64_t B, int32_t E, float temperature, float* loss,
+                         void* saved, size_t saved_bytes, void* stream) {
+  if (!emb || !labels || !loss || !saved || B <= 0 || E <= 0 || E > 1024 || !(temperature > 0.f)) return XNRS_EINVAL;
+  if (saved_bytes < xnrs_infonce_saved_bytes(B, E)) return XNRS_EWORKSPACE;
+  return hip_rc(launch_infonce_fwd(emb, labels, B, E, temperature, loss, static_cast<float*>(saved), (hipStream_t)stream));
+}
+
+int32_t xnrs_infonce_bwd(const int64_t* labels, int64_t B, int32_t E, float temperature, const void* saved, size_t saved_bytes,
+                         const float* gout, float* demb, void* stream) {
+  if (!labels || !saved || !gout || !demb || B <= 0 || E <= 0 || E > 1024 || !(temperature > 0.f)) return XNRS_EINVAL;
+  if (saved_bytes < xnrs_infonce_saved_bytes(B, E)) return XNRS_EWORKSPACE;
+  return hip_rc(launch_infonce_bwd(labels, B, E, temperature, static_cast<const float*>(saved), gout, demb, (hipStream_t)stream));
+}
+
+}  // extern "C"

@@ -203,4 +203,11 @@ hipError_t launch_score_csr(const float* vecs, const int32_t* rows, const int32_
 hipError_t launch_rank_metrics(const float* score, const float* target, const int64_t* off, float* out, int64_t B,
                                hipStream_t stream);
 
+// ---------------------------------------------------------------- in-batch InfoNCE (training.py:433-472)
+// ws: (B*E + 4*B + 1) floats = normalised embeddings | 1/norm | num | den | L_i | 1/(count+1e-8); kept for the backward
+hipError_t launch_infonce_fwd(const float* x, const int64_t* lab, int64_t B, int E, float temperature, float* loss, float* ws,
+                              hipStream_t stream);
+hipError_t launch_infonce_bwd(const int64_t* lab, int64_t B, int E, float temperature, const float* ws, const float* gout,
+                              float* dx, hipStream_t stream);
+
 }  // namespace xnrs

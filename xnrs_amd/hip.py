@@ -28,6 +28,7 @@ SYMBOLS = (
     "xnrs_seq_encoder_bwd", "xnrs_linear_bwd_workspace_bytes", "xnrs_linear_bwd",
     "xnrs_embedding_linear_bwd_workspace_bytes", "xnrs_embedding_linear_bwd", "xnrs_dot_scoring_bwd",
     "xnrs_assemble_train_batch", "xnrs_assemble_eval_batch", "xnrs_score_csr", "xnrs_rank_metrics",
+    "xnrs_infonce_saved_bytes", "xnrs_infonce_fwd", "xnrs_infonce_bwd",
 )
 POOL_NONE = -1
 PROFILE_STAGES = ("qkv_gemm", "attention_core", "out_gemm", "fc1_tanh_gemm", "pool", "head_gemms")
@@ -135,6 +136,12 @@ def lib():
     l.xnrs_score_csr.argtypes = [p, p, p, p, p, i64, i32, i32, p]
     l.xnrs_rank_metrics.restype = i32
     l.xnrs_rank_metrics.argtypes = [p, p, p, p, i64, p]
+    l.xnrs_infonce_saved_bytes.restype = sz
+    l.xnrs_infonce_saved_bytes.argtypes = [i64, i32]
+    l.xnrs_infonce_fwd.restype = i32
+    l.xnrs_infonce_fwd.argtypes = [p, p, i64, i32, f, p, p, sz, p]
+    l.xnrs_infonce_bwd.restype = i32
+    l.xnrs_infonce_bwd.argtypes = [p, i64, i32, f, p, sz, p, p, p]
     l.xnrs_profile_enable.restype = i32
     l.xnrs_profile_enable.argtypes = [C.c_uint32]
     l.xnrs_profile_read.restype = i32
