@@ -88,7 +88,9 @@ class NewsStore:
             x = np.fromfile(path + ".x.f32", dtype=np.float32).reshape(n, S, D)
             m = np.fromfile(path + ".m.u8", dtype=np.uint8).reshape(n, S)
         cols = {k: torch.from_numpy(np.fromfile(f"{path}.{k}.i32", dtype=np.int32)) for k in h["columns"]}
-        return cls(torch.from_numpy(np.ascontiguousarray(x)), torch.from_numpy(np.ascontiguousarray(m)).float(), h["ids"], cols)
+        # np.array(...) copies out of the read-only mapping page by page (no second whole-file buffer on top of
+        # the page cache); the caller then moves the tensors to the device once
+        return cls(torch.from_numpy(np.array(x)), torch.from_numpy(np.array(m)).float(), h["ids"], cols)
 
 
 def _csr(lists: List[List[int]]):
