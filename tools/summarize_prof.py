@@ -21,7 +21,7 @@ def main(root):
     if tr:
         d = defaultdict(list)
         for row in csv.DictReader(open(tr[0])):
-            key = short(row["Kernel_Name"]) + " grid=" + str(row.get("Grid_Size", row.get("Grid_Size_X", "?")))
+            key = short(row["Kernel_Name"]) + " grid=" + str(row.get("Grid_Size", row.get("Grid_Size_X", "?"))) + "x" + str(row.get("Grid_Size_Y", ""))
             d[key].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
         tot = sum(sum(v) for v in d.values())
         print("== kernel trace (ns) : name calls total_ms avg_us min_us max_us pct")

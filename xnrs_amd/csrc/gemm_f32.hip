@@ -532,9 +532,10 @@ size_t gemm_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K) {
 }
 
 int gemm_pick_splits(int64_t M, int64_t N, int64_t K) {
-  // aim for ~1024 workgroups of 128x128 and at least 256 contraction steps per slice
+  // aim for one round of 128x128 workgroups (2 per CU x 256 CUs for the k-major variants) and at least 256
+  // contraction steps per slice
   const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
-  int64_t ns = (1024 + tiles - 1) / tiles;
+  int64_t ns = 512 / tiles;
   const int64_t max_by_k = K / 256;
   if (ns > max_by_k) ns = max_by_k;
   if (ns > 64) ns = 64;
