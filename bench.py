@@ -232,6 +232,40 @@ def train_step_extra(device, steps=5, warmup=2):
     return dict(ms=dt * 1e3, impressions_per_s=w["B"] / dt, batch=w["B"], loss_finite=bool(torch.isfinite(fn()).item()))
 
 
+def eval_epoch_extra(device, n_news=20000, n_sess=20000):
+    """Evaluation path (xnrs_amd/evaluation.py): encode every news of a resident table ONCE, then score
+    impressions as CSR candidate lists + per-impression metrics on the device.  The reference's test loop
+    (training.py:61-67,194-243) runs batch_size 1 and re-encodes all candidates of every impression."""
+    import numpy as np
+    from xnrs_amd.data import Behaviors, NewsStore
+    from xnrs_amd.evaluation import evaluate
+    w = dict(B=1, H=25, C=5, S=50, D=768, h=16, E=256, A=256)
+    model, _ = build_model(w, device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(21)
+    x, m = synth.device_tokens(gen, n_news + 1, w["S"], w["D"], device)
+    x[0] = 0
+    m[0] = 0
+    store = NewsStore(x, m.reshape(n_news + 1, w["S"]), list(range(n_news)))
+    rng = np.random.default_rng(3)
+
+    def csr(lo, hi):
+        cnt = rng.integers(lo, hi + 1, size=n_sess)
+        off = np.zeros(n_sess + 1, dtype=np.int64)
+        np.cumsum(cnt, out=off[1:])
+        return torch.from_numpy(off).to(device), torch.from_numpy(rng.integers(1, n_news + 1, size=int(off[-1])).astype(np.int32)).to(device)
+    beh = Behaviors(csr(1, 40), csr(1, 3), csr(5, 60), ["t"] * n_sess)
+    beh.theme_labels = beh.theme_labels.to(device)
+    evaluate(model, store, beh, w["H"], batch=8192)  # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = evaluate(model, store, beh, w["H"], batch=8192)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dict(n_news=n_news, n_impressions=n_sess, candidates=int(beh.pos_off[-1] + beh.neg_off[-1]), seconds=dt,
+                impressions_per_s=n_sess / dt, auc=res["auc"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -335,6 +369,7 @@ def main():
                 out["extra"]["stage_tflops"] = {k: (v[2] / (v[0] * 1e-3) / 1e12 if v[0] > 0 else 0.0) for k, v in st.items()}
                 out["extra"]["other_models_fwd_B512_H25"] = other_models_extra(device)
             out["extra"]["nrms_train_step_B64"] = train_step_extra(device)
+            out["extra"]["eval_epoch"] = eval_epoch_extra(device)
         assert torch.isfinite(scores).all()
         print(json.dumps(out))
     if dist_on:

@@ -1,0 +1,173 @@
+"""The building blocks of the xnrs scoring path as thin nn.Module shells over HIP kernels.
+
+Every class keeps the NAME, CONSTRUCTOR SIGNATURE, PARAMETER NAMES / REGISTRATION ORDER and forward
+tensor contract of its counterpart in the reference's `xnrs.models.components` (cited per class), so
+checkpoints (`state_dict`) and callers are interchangeable; none of them computes anything in torch --
+`forward` is one call into `xnrs_amd.ops` (libxnrs_hip.so).  CPU tensors raise XnrsHipError.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+# ------------------------------------------------------------------------------------------- poolers / attention
+class MaskedMean(nn.Module):
+    """Reference: xnrs/models/components/layers.py:19-37.  (B,N,D),(B,N,1) -> (B,1,D) = sum(x*m)/(sum(m)+1e-8)."""
+
+    def forward(self, x: torch.Tensor, m: torch.Tensor):
+        return ops.masked_mean(x, m)
+
+
+class AdditiveAttention(nn.Module):
+    """Reference: layers.py:40-69.  fc1: Linear(in, hidden), fc2: Linear(hidden, 1); weights are
+    exp(fc2(tanh(fc1 x))) * m / (sum + 1e-8) -- un-stabilised exp, exactly as the reference."""
+
+    def __init__(self, in_features, hidden_features):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc2 = nn.Linear(hidden_features, 1)
+
+    def forward(self, x: torch.Tensor, m: torch.Tensor = None, return_weights: bool = False):
+        return ops.additive_attention(x, m, self, return_weights)
+
+
+class MultiHeadAttention(nn.Module):
+    """Reference: layers.py:105-156.  Four Linear(d_model, d_model) registered as q, v, k, (dropout), out;
+    query-ROW mask with -1e9 fill; Dropout(p) on the probabilities in train mode."""
+
+    def __init__(self, n_heads, d_model, dropout=0.1, scaled=True):
+        super().__init__()
+        self.h, self.d_model, self.d_k, self.scaled = n_heads, d_model, d_model // n_heads, scaled
+        for name in ("q_linear", "v_linear", "k_linear"):  # the reference's registration order
+            setattr(self, name, nn.Linear(d_model, d_model))
+        self.dropout = nn.Dropout(dropout)
+        self.out = nn.Linear(d_model, d_model)
+
+    def forward(self, x: torch.Tensor, m: torch.Tensor):
+        return ops.multi_head_attention(x, m, self)
+
+
+# ------------------------------------------------------------------------------------------- encoders
+def _mlp_head(n_in: int, n_out: int, activation: nn.Module, bias: bool) -> nn.Sequential:
+    if not isinstance(activation, nn.ReLU):
+        raise NotImplementedError("the HIP head kernel implements the reference default ReLU only")
+    return nn.Sequential(nn.Linear(n_in, n_out, bias=bias), activation, nn.Linear(n_out, n_out, bias=bias))
+
+
+class _Tower(nn.Module):
+    """What TextEncoder and UserEncoder share: dummy_param (so `.device` works for parameter-free towers),
+    input dropout, optional self-attention, pooler, optional MLP head -- in the reference's registration
+    order so state_dict keys line up."""
+
+    def _setup(self, p_dropout: float, att: Optional[nn.Module], pooler: nn.Module):
+        self.dummy_param = nn.Parameter(torch.zeros(1))
+        self.dropout = nn.Dropout(p=p_dropout)
+        self.att = att
+        self.pooler = pooler
+
+    def _to_own_device(self, *tensors):
+        dev = self.dummy_param.device
+        return tuple(t.to(dev) for t in tensors)
+
+
+class TextEncoder(_Tower):
+    """Reference: xnrs/models/components/news_encoding.py:8-60.
+    forward((x:(B,N,S,D), m:(B,N,S,1))) -> (y:(B,N,out_features), news mask:(B,N,1)).
+
+    Extension: forward_ids(table_x, table_m, ids) encodes news gathered by row id from a device-resident
+    token table (the gather is fused into the first GEMM's load)."""
+
+    def __init__(self, pooler: nn.Module, p_dropout: float, out_features: int, in_features: Optional[int] = 768,
+                 head: bool = True, activation: nn.Module = nn.ReLU(), att: Optional[nn.Module] = None, bias: bool = True):
+        super().__init__()
+        self._setup(p_dropout, att, pooler)
+        if head:
+            assert in_features is not None, 'in_features is required if head is True'
+            self.head = _mlp_head(in_features, out_features, activation, bias)
+        self.out_dim = out_features
+
+    def forward(self, inpt: tuple):
+        x, m = self._to_own_device(*inpt)
+        b, n, s, d = x.shape
+        y, hm = ops.text_encoder(self.dropout(x.reshape(b * n, s, d)), m.reshape(b * n, s, 1), self)
+        return y.reshape(b, n, self.out_dim), hm.reshape(b, n, 1)
+
+    def forward_ids(self, table_x: torch.Tensor, table_m: torch.Tensor, ids: torch.Tensor):
+        b, n = ids.shape
+        y, hm = ops.text_encoder(table_x, table_m, self, ids=ids.reshape(-1))
+        return y.reshape(b, n, self.out_dim), hm.reshape(b, n, 1)
+
+
+class UserEncoder(_Tower):
+    """Reference: xnrs/models/components/user_encoding.py:6-81 (head = Linear(E,E)-ReLU-Linear(E,E) as
+    committed at :26-34; `out_dim` and `add_features` are accepted and ignored exactly like the reference).
+    forward((x:(B,N,E), m:(B,N,1))) -> (B,1,E) [, pooling weights (B,N,1)]."""
+
+    def __init__(self, pooler: nn.Module, p_dropout: float, emb_dim: Optional[int] = None, out_dim: Optional[int] = None,
+                 att: Optional[nn.Module] = None, head: bool = False, activation: nn.Module = nn.ReLU(), bias: bool = True):
+        super().__init__()
+        self._setup(p_dropout, att, pooler)
+        if head:
+            assert emb_dim is not None
+            self.head = _mlp_head(emb_dim, emb_dim, activation, bias)
+
+    def forward(self, inpt: tuple, add_features: Optional[dict] = None, return_weights: bool = False):
+        x, m = self._to_own_device(*inpt)
+        return ops.user_encoder(self.dropout(x), m, self, return_weights)
+
+
+class DotScoring(nn.Module):
+    """Reference: xnrs/models/components/scoring.py:6-23.  u:(B,1,D), c:(B,N,D) -> (B,N,1)."""
+
+    def __init__(self, normalize: bool = False):
+        super().__init__()
+        self.normalize = normalize
+
+    def forward(self, u: torch.Tensor, c: torch.Tensor):
+        return ops.dot_scoring(u, c, self.normalize)
+
+
+# ------------------------------------------------------------------------------------------- bi-encoder shell
+class ParentRec(nn.Module):
+    """Reference: xnrs/models/components/parent.py:8-81: news tower over history and candidates, user tower
+    over the history vectors, scorer."""
+
+    def __init__(self, news_encoder: nn.Module, user_encoder: nn.Module, rec_model: nn.Module, text_feature: str = 'title_emb'):
+        super().__init__()
+        self.news_encoder, self.user_encoder, self.rec_model = news_encoder, user_encoder, rec_model
+        self.text_feature = text_feature
+
+    def _score(self, h, hm, c, add_user_feats, return_embeddings):
+        u = self.user_encoder((h, hm), add_user_feats)
+        r = self.rec_model(u, c)
+        return (r, u, c) if return_embeddings else r
+
+    def _forward(self, history: Tuple[torch.Tensor], candidates: Tuple[torch.Tensor],
+                 add_user_feats: Optional[Tuple[torch.Tensor]] = None, return_embeddings: bool = False):
+        h, hm = self.news_encoder(history)
+        c, _ = self.news_encoder(candidates)
+        return self._score(h, hm, c, add_user_feats, return_embeddings)
+
+    def forward(self, batch: dict, return_embeddings: bool = False):
+        uf = batch['user_features']
+        return self._forward(uf['history'][self.text_feature], batch['candidate_features'][self.text_feature],
+                             uf['other'], return_embeddings)
+
+    def get_user_embeddings(self, batch: dict) -> torch.Tensor:
+        """(B, E) user embedding from the history alone -- what the contrastive loss consumes."""
+        history = batch['user_features']['history'][self.text_feature]
+        h, hm = self.news_encoder(tuple(history) if isinstance(history, list) else history)
+        return self.user_encoder((h, hm)).squeeze(1)
+
+    def forward_ids(self, table_x: torch.Tensor, table_m: torch.Tensor, hist_ids: torch.Tensor, cand_ids: torch.Tensor,
+                    return_embeddings: bool = False):
+        """Extension: impressions given as row ids into a device-resident token table (row 0 / any all-zero
+        row = the empty history slot)."""
+        h, hm = self.news_encoder.forward_ids(table_x, table_m, hist_ids)
+        c, _ = self.news_encoder.forward_ids(table_x, table_m, cand_ids)
+        return self._score(h, hm, c, None, return_embeddings)

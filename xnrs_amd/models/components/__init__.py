@@ -1,4 +1,3 @@
-from .news_encoding import TextEncoder
-from .user_encoding import UserEncoder
-from .parent import ParentRec
-from . import layers, scoring
+"""Same import surface as xnrs.models.components."""
+from ..blocks import ParentRec, TextEncoder, UserEncoder  # noqa: F401
+from . import layers, news_encoding, parent, scoring, user_encoding  # noqa: F401

@@ -1,5 +1,2 @@
-from .standard_model import StandardRec, BaseRec
-from .mean_model import MeanRec, ParamFreeRec
-from .nrms import NRMS, NRMS_LF
-from .naml import NAML
-from .lstur import LSTURNewsEncoder
+"""Same import surface as xnrs.models.full_models for the models on the hot path (xnrs_amd/models/assemblies.py)."""
+from ..assemblies import NAML, NRMS, NRMS_LF, BaseRec, LSTURNewsEncoder, MeanRec, ParamFreeRec, StandardRec  # noqa: F401
