@@ -202,3 +202,38 @@ def test_cpu_tensors_fail_loudly():
     pool = layers.AdditiveAttention(8, 4)  # left on the CPU
     with torch.no_grad(), pytest.raises(XnrsHipError):
         pool(torch.zeros(1, 2, 8), None)
+
+
+@pytest.mark.parametrize("with_ids", [False, True])
+def test_chunked_passes_equal_single_pass(with_ids):
+    """The chunk loop of xnrs_text_encoder_fwd (workspace-bounded passes) must not change a bit."""
+    from xnrs_amd import ops
+    c = cases.ENCODERS["news_nrms_300"]
+    D, E, S = c["D"], c["E"], c["S"]
+    enc, _ = load(news_encoding.TextEncoder(pooler=layers.AdditiveAttention(D, 256), p_dropout=0.0, out_features=E,
+                                             in_features=D, att=layers.MultiHeadAttention(c["h"], D)), 81)
+    rng = synth.rng_for(82)
+    tx, tm = synth.token_block(rng, 1, 23, S, D, min_len=2, full_pad_prob=0.1)
+    tx, tm = tx[0].to(DEV), tm[0].to(DEV)
+    ids = torch.from_numpy(rng.integers(0, 23, size=(37,)).astype("int32")).to(DEV) if with_ids else None
+    with torch.no_grad():
+        y0, hm0 = ops.text_encoder(tx, tm, enc, ids=ids, chunk=0)
+        for chunk in (1, 5, 16):
+            y1, hm1 = ops.text_encoder(tx, tm, enc, ids=ids, chunk=chunk)
+            assert torch.equal(y0, y1) and torch.equal(hm0, hm1), chunk
+
+
+def test_long_sequences_generic_attention_path():
+    """S = 100 (> 64): the generic one-wave-per-query-tile kernel; also d_k = 80 (> 64)."""
+    for (S, D, h) in ((100, 64, 4), (20, 160, 2)):
+        att, sd = load(layers.MultiHeadAttention(h, D), 91)
+        rng = synth.rng_for(92)
+        x = torch.from_numpy(rng.standard_normal((2, S, D)).astype("float32"))
+        m = torch.from_numpy(cases.block_mask(rng, 2, S))
+        with torch.no_grad():
+            y = att(x.to(DEV), m.to(DEV))
+        H.assert_close(y, O.multi_head_attention(x, m, sd, h), what=f"S={S} D={D}")
+    att = layers.MultiHeadAttention(2, 8).to(DEV)
+    from xnrs_amd.hip import XnrsHipError
+    with torch.no_grad(), pytest.raises(XnrsHipError):
+        att(torch.zeros(1, 129, 8, device=DEV), None)  # S > 128 is outside the supported range: loud, not wrong
