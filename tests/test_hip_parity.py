@@ -237,3 +237,34 @@ def test_long_sequences_generic_attention_path():
     from xnrs_amd.hip import XnrsHipError
     with torch.no_grad(), pytest.raises(XnrsHipError):
         att(torch.zeros(1, 129, 8, device=DEV), None)  # S > 128 is outside the supported range: loud, not wrong
+
+
+def test_forward_is_hipgraph_capturable():
+    """The C ABI promises: no allocation, no host sync, everything on the caller's stream -> a whole
+    ParentRec forward can be captured into a hipGraph and replayed (small-batch / eval latency path)."""
+    c = cases.MODELS["nrms_300"]
+    model, sd = load(make_model(Cfg(cases.model_cfg(c))), c["seed"] + 1)
+    batch = synth.batch_to(cases.model_batch(c), DEV)
+    hist = batch["user_features"]["history"]["title_emb"]
+    cand = batch["candidate_features"]["title_emb"]
+    static_h = tuple(t.clone() for t in hist)
+    static_c = tuple(t.clone() for t in cand)
+    with torch.no_grad():
+        ref = model._forward(hist, cand)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                model._forward(static_h, static_c)  # warm-up on the side stream (workspace allocation)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = model._forward(static_h, static_c)
+        static_h[0].zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert not torch.equal(out, ref)  # inputs changed -> the replay really recomputed
+        static_h[0].copy_(hist[0])
+        g.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(out, ref)
