@@ -266,6 +266,26 @@ def eval_epoch_extra(device, n_news=20000, n_sess=20000):
                 impressions_per_s=n_sess / dt, auc=res["auc"])
 
 
+def latency_extra(device, reps=50):
+    """Launch-bound regime: ONE impression (H=25, C=5, S=50, D=768) -- ~15 kernel launches -- eager vs a
+    captured hipGraph replay (the C ABI allocates nothing and syncs nothing, so the forward is capturable)."""
+    w = dict(B=1, H=25, C=5, S=50, D=768, h=16, E=256, A=256)
+    model, _ = build_model(w, device)
+    hist, cand = make_inputs(w, device, seed=3)
+    fn = lambda: model._forward(hist, cand)  # noqa: E731
+    eager = timed(fn, reps, 10, False) / reps
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    graph = timed(g.replay, reps, 10, False) / reps
+    return dict(eager_ms=eager * 1e3, hipgraph_ms=graph * 1e3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -368,6 +388,7 @@ def main():
                 out["extra"]["stage_ms_per_step"] = {k: round(v[0], 3) for k, v in st.items()}
                 out["extra"]["stage_tflops"] = {k: (v[2] / (v[0] * 1e-3) / 1e12 if v[0] > 0 else 0.0) for k, v in st.items()}
                 out["extra"]["other_models_fwd_B512_H25"] = other_models_extra(device)
+                out["extra"]["latency_one_impression"] = latency_extra(device)
             out["extra"]["nrms_train_step_B64"] = train_step_extra(device)
             out["extra"]["eval_epoch"] = eval_epoch_extra(device)
         assert torch.isfinite(scores).all()

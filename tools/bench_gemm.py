@@ -14,8 +14,13 @@ from xnrs_amd import hip, ops  # noqa: E402
 
 dev = torch.device("cuda", 0)
 shapes = [(65500, 2304, 768), (65500, 768, 768), (30720, 960, 320)]
-names = sys.argv[1].split(",") if len(sys.argv) > 1 else ["p1k32g", "p5k32b", "p5k16b", "p6k16b"]
-variants = {v: {"XNRS_GEMM_PIPE": v[1], "XNRS_GEMM_BK": v[3:5], "XNRS_GEMM_BUF": "1" if v[5] == "b" else "0"} for v in names}
+# variants: "name:ENV=v+ENV=v,name2:..."; default compares the plain double-buffered pipeline with the default one
+spec = sys.argv[1] if len(sys.argv) > 1 else "p1k32:XNRS_GEMM_PIPE=1+XNRS_GEMM_BK=32,default:,p5k32:XNRS_GEMM_PIPE=5+XNRS_GEMM_BK=32,p5k16_3wg:XNRS_GEMM_PIPE=5+XNRS_GEMM_BK=16"
+variants = {}
+for item in spec.split(","):
+    name, _, envs = item.partition(":")
+    variants[name] = dict(e.split("=") for e in envs.split("+") if e)
+ALL_KEYS = ("XNRS_GEMM_PIPE", "XNRS_GEMM_BK", "XNRS_GEMM_BUF")
 torch.manual_seed(0)
 for (M, N, K) in shapes:
     x = torch.randn(M, K, device=dev)
@@ -25,6 +30,8 @@ for (M, N, K) in shapes:
     res = {v: [] for v in variants}
     for rnd in range(5):
         for v, env in variants.items():
+            for k in ALL_KEYS:
+                os.environ.pop(k, None)
             os.environ.update(env)
             y = ops.linear(x, w, b)  # warm
             if rnd == 0:

@@ -49,7 +49,8 @@ __device__ __attribute__((aligned(16))) float g_zero_line[4] = {0.f, 0.f, 0.f, 0
 //   5: the same two LDS buffers and ONE register set, but an explicitly interleaved instruction stream
 //      (default; 130-136 TF).  Measured alternatives that were dropped: two register sets / LDS store
 //      mid-stream without interleave 121 TF; three LDS buffers with cross-barrier fragment prefetch at one
-//      workgroup per CU 112 TF, at two per CU 130 TF.
+//      workgroup per CU 112 TF, at two per CU 130 TF; 128x256 / 256x128 block tiles (2 waves/SIMD) 131 TF
+//      against 133 TF for the default on the same device.
 // BUF: tile loads are raw buffer loads (ROW/WT layouts, no gather, operands <= 1 GB): the row offset is a
 // loop-invariant 32-bit VGPR, the k offset rides in the scalar offset, and out-of-range rows / k chunks
 // are handled by the hardware bounds check (offset bit 30 set -> beyond num_records -> returns 0).  The
