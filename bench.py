@@ -70,8 +70,8 @@ def impression_bytes(w):
     return (w["H"] + w["C"]) * per_news + 4 * w["C"]
 
 
-def build_model(w, device, seed=1234):
-    c = dict(model="NRMS", E=w["E"], bias=False, h=w["h"], D=w["D"], H=w["H"], S=w["S"])
+def build_model(w, device, seed=1234, model_name="NRMS"):
+    c = dict(model=model_name, E=w["E"], bias=False, h=w["h"], D=w["D"], H=w["H"], S=w["S"])
     model = make_model(Cfg(cases.model_cfg(c)))
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     sd = synth.fill_state_dict(shapes, seed)
@@ -205,12 +205,12 @@ def other_models_extra(device, steps=5, warmup=2):
     return out
 
 
-def train_step_extra(device, steps=5, warmup=2):
+def train_step_extra(device, steps=5, warmup=2, model_name="NRMS"):
     """The grad step of the reference (training.py:402-431) on the HIP path: NRMS at the shipped
     config (batch 64, H=25, C=5, S=50, D=768, train-mode attention dropout 0.1), forward + relu/MSE +
     lambda*InfoNCE on a second history encode + backward + Adam."""
     w = dict(B=64, H=25, C=5, S=50, D=768, h=16, E=256, A=256)
-    model, _ = build_model(w, device)
+    model, _ = build_model(w, device, model_name=model_name)
     model.train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
     hist, cand = make_inputs(w, device, seed=7)
@@ -390,6 +390,7 @@ def main():
                 out["extra"]["other_models_fwd_B512_H25"] = other_models_extra(device)
                 out["extra"]["latency_one_impression"] = latency_extra(device)
             out["extra"]["nrms_train_step_B64"] = train_step_extra(device)
+            out["extra"]["standard_train_step_B64"] = train_step_extra(device, model_name="standard")
             out["extra"]["eval_epoch"] = eval_epoch_extra(device)
         assert torch.isfinite(scores).all()
         print(json.dumps(out))

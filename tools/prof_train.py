@@ -10,5 +10,6 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 dev = torch.device("cuda", 0)
-r = bench.train_step_extra(dev, steps=int(sys.argv[1]) if len(sys.argv) > 1 else 3, warmup=1)
+r = bench.train_step_extra(dev, steps=int(sys.argv[1]) if len(sys.argv) > 1 else 3, warmup=1,
+                           model_name=sys.argv[2] if len(sys.argv) > 2 else "NRMS")
 print(r)
