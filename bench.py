@@ -266,6 +266,37 @@ def eval_epoch_extra(device, n_news=20000, n_sess=20000):
                 impressions_per_s=n_sess / dt, auc=res["auc"])
 
 
+def id_path_extra(device, steps=5, warmup=2, n_news=65536):
+    """The device-resident news table path (ParentRec.forward_ids): B=512 impressions given as row ids into a
+    65 536-news table (10 GB, MIND-small scale), ids ~ Zipf(1.1); the gather happens in the
+    first GEMM's load.  `dedup` encodes each distinct news of the step once -- less algorithmic work, hence
+    reported separately from the headline value."""
+    import numpy as np
+    w = WORKLOAD
+    model, _ = build_model(w, device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(31)
+    tx, tm = synth.device_tokens(gen, n_news + 1, w["S"], w["D"], device)
+    tx[0] = 0
+    tm[0] = 0
+    tm = tm.reshape(n_news + 1, w["S"])
+    rng = np.random.default_rng(5)
+    z = np.minimum(rng.zipf(1.1, size=(w["B"], w["H"] + w["C"])), n_news).astype(np.int32)
+    n_hist = rng.integers(1, w["H"] + 1, size=(w["B"], 1))
+    z[:, :w["H"]][np.arange(w["H"])[None, :] >= n_hist] = 0  # empty history slots
+    ids = torch.from_numpy(z).to(device)
+    hist_ids, cand_ids = ids[:, :w["H"]].contiguous(), ids[:, w["H"]:].contiguous()
+    out = {"table_news": n_news, "distinct_ids_in_step": int(torch.unique(ids).numel()), "ids_in_step": int(ids.numel())}
+    for name, dd in (("gather", False), ("gather_dedup", True)):
+        fn = lambda: model.forward_ids(tx, tm, hist_ids, cand_ids, dedup=dd)  # noqa: E731
+        dt = timed(fn, steps, warmup, False) / steps
+        out[name] = dict(impressions_per_s=w["B"] / dt, ms=dt * 1e3)
+    r0 = model.forward_ids(tx, tm, hist_ids, cand_ids)
+    r1 = model.forward_ids(tx, tm, hist_ids, cand_ids, dedup=True)
+    out["dedup_equals_plain"] = bool(torch.equal(r0, r1))
+    return out
+
+
 def latency_extra(device, reps=50):
     """Launch-bound regime: ONE impression (H=25, C=5, S=50, D=768) -- ~15 kernel launches -- eager vs a
     captured hipGraph replay (the C ABI allocates nothing and syncs nothing, so the forward is capturable)."""
@@ -389,6 +420,7 @@ def main():
                 out["extra"]["stage_tflops"] = {k: (v[2] / (v[0] * 1e-3) / 1e12 if v[0] > 0 else 0.0) for k, v in st.items()}
                 out["extra"]["other_models_fwd_B512_H25"] = other_models_extra(device)
                 out["extra"]["latency_one_impression"] = latency_extra(device)
+                out["extra"]["id_path_B512"] = id_path_extra(device)
             out["extra"]["nrms_train_step_B64"] = train_step_extra(device)
             out["extra"]["standard_train_step_B64"] = train_step_extra(device, model_name="standard")
             out["extra"]["eval_epoch"] = eval_epoch_extra(device)

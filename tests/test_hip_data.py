@@ -136,3 +136,22 @@ def test_host_tensors_fail_loudly():
     news_feat, sessions, store, beh = setup()
     with pytest.raises(XnrsHipError):
         DeviceBatcher(beh, 5)
+
+
+def test_dedup_equals_plain_id_path():
+    news_feat, sessions, store, beh = setup()
+    c = cases.DATA
+    model, sd, mc = model_for(c)
+    dstore = store.to(DEV)
+    bat = DeviceBatcher(beh.to(DEV), c["l_hist"])
+    sess = torch.tensor([0, 1, 2, 3, 4, 5, 1, 1], device=DEV)
+    hist, cand, _ = bat.train_batch(sess, c["n_neg"], seed=3)
+    with torch.no_grad():
+        r0, u0, c0 = model.forward_ids(dstore.x, dstore.m, hist, cand, return_embeddings=True)
+        r1, u1, c1 = model.forward_ids(dstore.x, dstore.m, hist, cand, return_embeddings=True, dedup=True)
+    assert torch.equal(r0, r1) and torch.equal(u0, u1) and torch.equal(c0, c1)
+    # gradients flow through the dedup scatter as well
+    model.train()
+    r = model.forward_ids(dstore.x, dstore.m, hist, cand, dedup=True)
+    r.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in model.named_parameters() if "dummy" not in n)

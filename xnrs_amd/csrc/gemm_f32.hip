@@ -490,7 +490,8 @@ static hipError_t launch_cfg(const GemmArgs& a, bool vec, int nsplit, hipStream_
     else if (pipe == 5 && buf) XNRS_LAUNCH(true, 5, 32, true, 2);
     else if (pipe == 5) XNRS_LAUNCH(true, 5, 32, false, 2);
     else if (buf) XNRS_LAUNCH(true, 5, 16, true, 4);
-    else XNRS_LAUNCH(true, 5, 16, false, 4);
+    else XNRS_LAUNCH(true, 5, 16, false, 3);  // 64-bit row pointers (gather / >1 GB operands): 139 VGPRs, 45 spills
+                                               // under the 128 cap -> 3 workgroups per CU instead
   } else if constexpr (!A_COL && !B_KN) {
     // the smaller forward tiles use the main tile's configuration too (BK 16, registers capped for 4 WG/CU):
     // +19..25 % on the Q/K/V projection at D = 300 / 320 against BK 32 at 2 WG/CU

@@ -97,9 +97,17 @@ class TextEncoder(_Tower):
         y, hm = ops.text_encoder(self.dropout(x.reshape(b * n, s, d)), m.reshape(b * n, s, 1), self)
         return y.reshape(b, n, self.out_dim), hm.reshape(b, n, 1)
 
-    def forward_ids(self, table_x: torch.Tensor, table_m: torch.Tensor, ids: torch.Tensor):
+    def forward_ids(self, table_x: torch.Tensor, table_m: torch.Tensor, ids: torch.Tensor, dedup: bool = False):
+        """dedup=True encodes every distinct row once and scatters the vectors back (SURVEY.md section 8f rank 1:
+        "unique-news dedup per step"); it changes the algorithmic work, so benchmarks report it separately."""
         b, n = ids.shape
-        y, hm = ops.text_encoder(table_x, table_m, self, ids=ids.reshape(-1))
+        flat = ids.reshape(-1)
+        if dedup:
+            uniq, inv = torch.unique(flat, return_inverse=True)  # index bookkeeping only
+            y, hm = ops.text_encoder(table_x, table_m, self, ids=uniq)
+            y, hm = y[inv], hm[inv]
+        else:
+            y, hm = ops.text_encoder(table_x, table_m, self, ids=flat)
         return y.reshape(b, n, self.out_dim), hm.reshape(b, n, 1)
 
 
@@ -165,9 +173,15 @@ class ParentRec(nn.Module):
         return self.user_encoder((h, hm)).squeeze(1)
 
     def forward_ids(self, table_x: torch.Tensor, table_m: torch.Tensor, hist_ids: torch.Tensor, cand_ids: torch.Tensor,
-                    return_embeddings: bool = False):
+                    return_embeddings: bool = False, dedup: bool = False):
         """Extension: impressions given as row ids into a device-resident token table (row 0 / any all-zero
-        row = the empty history slot)."""
-        h, hm = self.news_encoder.forward_ids(table_x, table_m, hist_ids)
-        c, _ = self.news_encoder.forward_ids(table_x, table_m, cand_ids)
-        return self._score(h, hm, c, None, return_embeddings)
+        row = the empty history slot).  dedup=True encodes each distinct news of the step once."""
+        if dedup:
+            H = hist_ids.shape[1]
+            both = torch.cat([hist_ids, cand_ids], dim=1)
+            v, vm = self.news_encoder.forward_ids(table_x, table_m, both, dedup=True)
+            h, hm, c = v[:, :H], vm[:, :H], v[:, H:]
+        else:
+            h, hm = self.news_encoder.forward_ids(table_x, table_m, hist_ids)
+            c, _ = self.news_encoder.forward_ids(table_x, table_m, cand_ids)
+        return self._score(h.contiguous(), hm.contiguous(), c.contiguous(), None, return_embeddings)
