@@ -232,6 +232,21 @@ int32_t xnrs_infonce_bwd(const int64_t *labels, int64_t B, int32_t E, float temp
 int32_t xnrs_profile_enable(uint32_t stage_mask);
 int32_t xnrs_profile_read(double *ms, int64_t *launches, double *flops);
 
+/* ---- arithmetic mode of the forward GEMMs (nn.Linear call sites listed at xnrs_linear_fwd) ----------
+ *   XNRS_GEMM_F32     (0, default) v_mfma_f32_32x32x2_f32: an exact fp32 fmaf chain.
+ *   XNRS_GEMM_BF16X3  (1) each fp32 operand is split exactly into three bf16 pieces and the product is
+ *                     rebuilt from six v_mfma_f32_32x32x16_bf16 with fp32 accumulation: dropped terms are
+ *                     <= 2^-26 |a||b| per product, i.e. below one fp32 rounding (measured on the full
+ *                     workload: same distance to the CPU oracle as mode 0).
+ *   XNRS_GEMM_BF16X2  (2) two pieces, three products: ~1e-5 relative per product; an opt-in speed knob.
+ * Process-wide; the initial value comes from the environment variable XNRS_GEMM_MODE.  The backward
+ * GEMMs always run in mode 0.  Returns the previous mode; values outside 0..2 select 0. */
+#define XNRS_GEMM_F32 0
+#define XNRS_GEMM_BF16X3 1
+#define XNRS_GEMM_BF16X2 2
+int32_t xnrs_set_gemm_mode(int32_t mode);
+int32_t xnrs_get_gemm_mode(void);
+
 #ifdef __cplusplus
 }
 #endif

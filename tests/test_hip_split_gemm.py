@@ -1,0 +1,159 @@
+"""GPU tests of the bf16-split forward GEMM modes (include/xnrs_hip.h: xnrs_set_gemm_mode).
+
+Mode 1 (bf16x3, six products) must be fp32-grade: as close to an fp64 product as the fp32 MFMA kernel is,
+and inside the 1e-4 parity bar against the golden vectors of the real reference.  Mode 2 (bf16x2, three
+products) is an opt-in speed knob held to the parity bar only."""
+import os
+
+import pytest
+import torch
+
+from tests import helpers as H
+from tests.golden import cases
+from xnrs_amd import hip, ops, synth
+from xnrs_amd.models import make_model
+from xnrs_amd.models.components import layers, news_encoding
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+@pytest.fixture
+def split_mode():
+    """-> setter; forces the split kernel onto every forward GEMM (also the tiny golden shapes) and restores."""
+    prev = hip.get_gemm_mode()
+    old = os.environ.get("XNRS_GEMM_SPLIT_MIN_TILES")
+    os.environ["XNRS_GEMM_SPLIT_MIN_TILES"] = "0"
+    yield hip.set_gemm_mode
+    hip.set_gemm_mode(prev)
+    if old is None:
+        os.environ.pop("XNRS_GEMM_SPLIT_MIN_TILES", None)
+    else:
+        os.environ["XNRS_GEMM_SPLIT_MIN_TILES"] = old
+
+
+def _fp64_err(y, x, w, b, act):
+    """max |y - ref| / (|x| . |w|^T + |b|): the normwise error a dot product is entitled to (a result that cancels to
+    ~0 is not held to a relative bar; relu / tanh are 1-Lipschitz, so the pre-activation bound carries over)."""
+    ref = x.double() @ w.double().t()
+    mag = x.double().abs() @ w.double().abs().t()
+    if b is not None:
+        ref = ref + b.double()
+        mag = mag + b.double().abs()
+    if act == hip.ACT_RELU:
+        ref = ref.clamp_min(0)
+    elif act == hip.ACT_TANH:
+        ref = ref.tanh()
+    return ((y.double() - ref).abs() / mag.clamp_min(1e-300)).max().item()
+
+
+# (M, N, K): full tiles; ragged M / N; K tails (K % 16 = 12, K % 8 = 4); tiny
+SHAPES = [(8200, 1000, 768), (4099, 260, 300), (130, 129, 36), (1, 1, 4), (257, 384, 256)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("act", [hip.ACT_NONE, hip.ACT_RELU, hip.ACT_TANH])
+def test_linear_modes_against_fp64(split_mode, shape, act):
+    M, N, K = shape
+    g = torch.Generator(device=DEV)
+    g.manual_seed(M + N + K)
+    x = torch.randn(M, K, device=DEV, generator=g) * 3.0
+    w = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5
+    b = torch.randn(N, device=DEV, generator=g) if act != hip.ACT_RELU else None
+    err = {}
+    for mode in (0, 1, 2):
+        split_mode(mode)
+        y = ops.linear(x, w, b, act)
+        assert torch.isfinite(y).all()
+        err[mode] = _fp64_err(y, x, w, b, act)
+    assert err[0] <= 1e-6, err
+    assert err[1] <= max(2e-7, 1.5 * err[0]), f"bf16x3 is not fp32-grade: {err}"
+    assert err[2] <= 1.5e-5, err  # 3 * 2^-18 = 1.1e-5 per product
+
+
+def test_split_handles_wide_dynamic_range(split_mode):
+    """bf16 pieces keep the fp32 exponent range: tiny and huge magnitudes in one row, exact zeros, negatives."""
+    g = torch.Generator(device=DEV)
+    g.manual_seed(5)
+    M, N, K = 512, 256, 128
+    x = torch.randn(M, K, device=DEV, generator=g)
+    x[:, ::7] *= 1e18
+    x[:, 1::7] *= 1e-18
+    x[:, 2::7] = 0.0
+    w = torch.randn(N, K, device=DEV, generator=g)
+    w[:, ::5] *= 1e-12
+    split_mode(0)
+    y0 = ops.linear(x, w)
+    split_mode(1)
+    y1 = ops.linear(x, w)
+    e0, e1 = _fp64_err(y0, x, w, None, 0), _fp64_err(y1, x, w, None, 0)
+    # both far inside the fp32 bound K * 2^-24 = 7.6e-6 of a sequential sum (measured 2.4e-7 / 5.5e-7)
+    assert e0 <= 1e-6 and e1 <= 1e-6, (e0, e1)
+
+
+def test_gather_rows_under_split(split_mode):
+    c = cases.ENCODERS["news_nrms_300"]
+    D, E, S = c["D"], c["E"], c["S"]
+    enc = news_encoding.TextEncoder(pooler=layers.AdditiveAttention(D, 256), p_dropout=0.0, out_features=E,
+                                    in_features=D, att=layers.MultiHeadAttention(c["h"], D))
+    shapes = {k: tuple(v.shape) for k, v in enc.state_dict().items()}
+    enc.load_state_dict(synth.fill_state_dict(shapes, 21))
+    enc = enc.eval().to(DEV)
+    rng = synth.rng_for(22)
+    tx, tm = synth.token_block(rng, 1, 40, S, D, min_len=3)
+    tx, tm = tx[0].to(DEV), tm[0].to(DEV)
+    ids = torch.from_numpy(rng.integers(0, 40, size=(3, 7)).astype("int64")).to(DEV)
+    with torch.no_grad():
+        split_mode(0)
+        y0, _ = enc((tx[ids], tm[ids]))
+        for mode in (1, 2):
+            split_mode(mode)
+            y1, hm1 = enc.forward_ids(tx, tm, ids)   # 64-bit row pointers (pointer variant of the kernel)
+            y2, hm2 = enc((tx[ids], tm[ids]))         # buffer-load variant
+            assert torch.equal(y1, y2) and torch.equal(hm1, hm2)
+            H.assert_close(y1, y0, tol=1e-5 if mode == 1 else 1e-4, what=f"mode {mode} vs fp32 MFMA")
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("name", sorted(cases.MODELS))
+def test_golden_models_under_split(split_mode, mode, name):
+    """The golden vectors of the real reference, with every forward GEMM on the split kernel."""
+    g = H.golden("models")
+    c = cases.MODELS[name]
+    model = make_model(Cfg(cases.model_cfg(c)))
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(synth.fill_state_dict(shapes, c["seed"] + 1))
+    model = model.eval().to(DEV)
+    batch = cases.model_batch(c)
+    split_mode(mode)
+    with torch.no_grad():
+        if c["model"] == "NAML":
+            H.assert_close(model(batch), g[f"{name}/r"], what=name)
+            return
+        r, u, cc = model(batch, return_embeddings=True)
+    H.assert_close(r, g[f"{name}/r"], what=name + " scores")
+    H.assert_close(u, g[f"{name}/u"], what=name + " user")
+    H.assert_close(cc, g[f"{name}/c"], what=name + " cand")
+
+
+def test_benchmark_shape_scores_under_split(split_mode):
+    """64 impressions of the benchmark shape (H=50, C=5, S=50, D=768): the split modes against the fp32 MFMA path
+    (itself pinned to the oracle at this shape by test_hip_parity / bench.py's parity field)."""
+    import bench
+    w = dict(bench.WORKLOAD, B=64)
+    model, _ = bench.build_model(w, torch.device(DEV))
+    hist, cand = bench.make_inputs(w, torch.device(DEV), seed=11)
+    with torch.no_grad():
+        split_mode(0)
+        r0 = bench.step(model, hist, cand)
+        os.environ.pop("XNRS_GEMM_SPLIT_MIN_TILES", None)  # the shipping dispatch rule
+        split_mode(1)
+        r1 = bench.step(model, hist, cand)
+        split_mode(2)
+        r2 = bench.step(model, hist, cand)
+    H.assert_close(r1, r0, tol=5e-6, what="bf16x3 vs fp32 MFMA")
+    H.assert_close(r2, r0, tol=1e-4, what="bf16x2 vs fp32 MFMA")

@@ -365,6 +365,14 @@ int32_t xnrs_user_encoder_fwd(const float* x, const float* m, int64_t B, int32_t
                     (hipStream_t)stream);
 }
 
+int32_t xnrs_set_gemm_mode(int32_t mode) {
+  const int prev = xnrs::gemm_mode();
+  xnrs::set_gemm_mode(mode);
+  return prev;
+}
+
+int32_t xnrs_get_gemm_mode(void) { return xnrs::gemm_mode(); }
+
 int32_t xnrs_profile_enable(uint32_t stage_mask) {
   for (auto& r : g_prof) {
     (void)hipEventDestroy(r.beg);

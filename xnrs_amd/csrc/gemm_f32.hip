@@ -547,6 +547,16 @@ int gemm_pick_splits(int64_t M, int64_t N, int64_t K) {
   return (int)ns;
 }
 
+static int g_gemm_mode = -1;
+int gemm_mode() {
+  if (g_gemm_mode < 0) {
+    const char* e = getenv("XNRS_GEMM_MODE");
+    g_gemm_mode = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 0;
+  }
+  return g_gemm_mode;
+}
+void set_gemm_mode(int mode) { g_gemm_mode = (mode >= 0 && mode <= 2) ? mode : 0; }
+
 hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t stream) {
   GemmArgs a = a_in;
   if (a.M <= 0 || a.Nseg <= 0) return hipSuccess;
@@ -571,6 +581,14 @@ hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t stream) {
     a.k_per_split = a.K > 0 ? a.K : 1;
   }
   hipError_t e;
+  const int mode = gemm_mode();
+  // the split kernel has one tile shape (128x128): below one full round of workgroups the fp32 kernel with its
+  // smaller tiles is faster (measured: 4099 x 260 x 300 -> 38 TF fp32 vs 22 TF split)
+  const char* mte = getenv("XNRS_GEMM_SPLIT_MIN_TILES");  // tests force the split kernel onto tiny shapes with 0
+  const int64_t min_tiles = mte ? atoll(mte) : 512;
+  if (mode && !a.a_col && !a.b_kn && vec && nsplit == 1 &&
+      ((a.M + 127) / 128) * ((a.Nseg + 127) / 128) * a.nseg >= min_tiles)
+    return launch_gemm_split(a, mode == 1 ? 3 : 2, stream);
   if (!a.a_col && !a.b_kn) e = launch_layout<false, false>(a, vec, nsplit, stream);
   else if (!a.a_col && a.b_kn) e = launch_layout<false, true>(a, vec, nsplit, stream);
   else if (a.a_col && a.b_kn) e = launch_layout<true, true>(a, vec, nsplit, stream);

@@ -45,6 +45,12 @@ struct GemmArgs {
 int gemm_pick_splits(int64_t M, int64_t N, int64_t K);
 size_t gemm_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
 hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t stream);
+// forward-layout GEMM on the bf16 matrix cores by operand splitting (gemm_split.hip); npl = 3 or 2 planes
+hipError_t launch_gemm_split(const GemmArgs& a, int npl, hipStream_t stream);
+// 0: exact fp32 MFMA (default); 1: bf16x3 split, six products (fp32-grade); 2: bf16x2 split, three products.
+// Initialised from XNRS_GEMM_MODE; applies to the forward (ROW x WT) layout only.
+int gemm_mode();
+void set_gemm_mode(int mode);
 
 // ---------------------------------------------------------------- attention core (QK^T, row mask, softmax, PV)
 struct MhaCoreArgs {

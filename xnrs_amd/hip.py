@@ -24,6 +24,7 @@ SYMBOLS = (
     "xnrs_additive_workspace_bytes", "xnrs_additive_attention_fwd", "xnrs_masked_mean_fwd", "xnrs_collapse_mask",
     "xnrs_text_encoder_workspace_bytes", "xnrs_text_encoder_fwd", "xnrs_user_encoder_workspace_bytes",
     "xnrs_user_encoder_fwd", "xnrs_dot_scoring_fwd", "xnrs_profile_enable", "xnrs_profile_read",
+    "xnrs_set_gemm_mode", "xnrs_get_gemm_mode",
     "xnrs_seq_encoder_saved_bytes", "xnrs_seq_encoder_fwd_train", "xnrs_seq_encoder_bwd_workspace_bytes",
     "xnrs_seq_encoder_bwd", "xnrs_linear_bwd_workspace_bytes", "xnrs_linear_bwd",
     "xnrs_embedding_linear_bwd_workspace_bytes", "xnrs_embedding_linear_bwd", "xnrs_dot_scoring_bwd",
@@ -142,6 +143,10 @@ def lib():
     l.xnrs_infonce_fwd.argtypes = [p, p, i64, i32, f, p, p, sz, p]
     l.xnrs_infonce_bwd.restype = i32
     l.xnrs_infonce_bwd.argtypes = [p, i64, i32, f, p, sz, p, p, p]
+    l.xnrs_set_gemm_mode.restype = i32
+    l.xnrs_set_gemm_mode.argtypes = [i32]
+    l.xnrs_get_gemm_mode.restype = i32
+    l.xnrs_get_gemm_mode.argtypes = []
     l.xnrs_profile_enable.restype = i32
     l.xnrs_profile_enable.argtypes = [C.c_uint32]
     l.xnrs_profile_read.restype = i32
@@ -160,6 +165,18 @@ def check(rc: int, what: str):
         # same exception type as the reference's failing .view() (layers.py:111,133)
         raise RuntimeError(f"{what}: {msg}")
     raise XnrsHipError(f"{what}: {msg} (code {rc})")
+
+
+GEMM_F32, GEMM_BF16X3, GEMM_BF16X2 = 0, 1, 2
+
+
+def set_gemm_mode(mode: int) -> int:
+    """Arithmetic of the forward GEMMs (include/xnrs_hip.h: xnrs_set_gemm_mode); returns the previous mode."""
+    return lib().xnrs_set_gemm_mode(int(mode))
+
+
+def get_gemm_mode() -> int:
+    return lib().xnrs_get_gemm_mode()
 
 
 def profile_enable(stage_mask: int):
