@@ -40,6 +40,10 @@ from xnrs_amd import hip, synth  # noqa: E402
 from xnrs_amd.models import make_model  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense, same table
+# forward-GEMM arithmetic modes (include/xnrs_hip.h: xnrs_set_gemm_mode): name, bf16 MFMA products per fp32 product
+GEMM_MODES = {0: ("f32", 1), 1: ("f32 via bf16x3 split operands (6 bf16 MFMA products, fp32 accumulate)", 6),
+              2: ("f32 via bf16x2 split operands (3 bf16 MFMA products, fp32 accumulate)", 3)}
 HBM_PEAK_GBS = 8000.0
 
 WORKLOAD = dict(B=512, H=50, C=5, S=50, D=768, h=16, E=256, A=256)
@@ -297,6 +301,34 @@ def id_path_extra(device, steps=5, warmup=2, n_news=65536):
     return out
 
 
+def gemm_modes_extra(model, hist, cand, steps, scores_f32, cpu_sample):
+    """The same step with the forward GEMMs on the bf16 matrix cores by operand splitting (opt-in modes 1 and 2):
+    throughput, per-stage time, distance of the scores to the fp32-MFMA scores of the headline run (full batch)
+    and, when the CPU baseline ran, to the CPU oracle on its sample."""
+    out = {}
+    B = hist[0].shape[0]
+    for mode in (1, 2):
+        hip.set_gemm_mode(mode)
+        fn = lambda: step(model, hist, cand)  # noqa: E731
+        dt = timed(fn, steps, 2, False)
+        hip.profile_enable(0x3F)
+        r = fn()
+        torch.cuda.synchronize()
+        st = hip.profile_read()
+        hip.profile_enable(0)
+        e = {"impressions_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3,
+             "stage_ms_per_step": {k: round(v[0], 3) for k, v in st.items()},
+             "qkv_gemm_alg_tflops": st["qkv_gemm"][2] / (st["qkv_gemm"][0] * 1e-3) / 1e12,
+             "max_rel_diff_vs_f32_mfma_scores": ((r - scores_f32).abs().max() / scores_f32.abs().max()).item()}
+        if cpu_sample is not None:
+            b, ref = cpu_sample
+            got = model._forward(b["user_features"]["history"]["title_emb"], b["candidate_features"]["title_emb"])
+            e["parity_max_rel_err_vs_cpu"] = (got.cpu().double() - ref.double()).abs().max().item() / ref.abs().max().item()
+        out[GEMM_MODES[mode][0].split(" via ")[1].split(" ")[0]] = e
+    hip.set_gemm_mode(0)
+    return out
+
+
 def latency_extra(device, reps=50):
     """Launch-bound regime: ONE impression (H=25, C=5, S=50, D=768) -- ~15 kernel launches -- eager vs a
     captured hipGraph replay (the C ABI allocates nothing and syncs nothing, so the forward is capturable)."""
@@ -324,6 +356,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--gemm-mode", type=int, default=0, choices=(0, 1, 2),
+                    help="arithmetic of the forward GEMMs for the HEADLINE line: 0 exact fp32 MFMA (default), "
+                         "1 bf16x3 split, 2 bf16x2 split; the default run reports modes 1 and 2 under extra")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -340,6 +375,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
+    hip.set_gemm_mode(args.gemm_mode)  # explicit: the environment (XNRS_GEMM_MODE) never changes the headline
+    mode_name, mode_products = GEMM_MODES[args.gemm_mode]
     w = WORKLOAD
     model, sd = build_model(w, device)
     hist, cand = make_inputs(w, device, seed=1000 + rank)  # each rank = its own shard of users
@@ -379,16 +416,23 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": mode_name,
             "data": "synthetic",
             "config": {"workload": "NRMS full user+news encode + 5-candidate dot scoring "
                                    "(BASELINE configs[2]; token shape of config/mind_small_NRMS.yml)",
                        "batch_impressions_per_gpu": w["B"], "history": w["H"], "candidates": w["C"],
                        "tokens": w["S"], "d_backbone": w["D"], "n_heads": w["h"], "emb_dim": w["E"],
                        "parallelism": f"impressions sharded by user over {n_gpus} GPU(s), no data-path collective"},
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "gemm_f32_kernel<2,2,true> (fused Q/K/V projection)",
+            # modes 1/2 issue `mode_products` bf16 MFMA products per algorithmic fp32 product: achieved = issued
+            # matrix flops against the dense bf16 peak
+            "roofline": {"bound": "mfma", "achieved": ach * mode_products,
+                         "peak": FP32_MFMA_PEAK_TFLOPS if args.gemm_mode == 0 else BF16_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s",
+                         "frac": ach * mode_products / (FP32_MFMA_PEAK_TFLOPS if args.gemm_mode == 0 else BF16_MFMA_PEAK_TFLOPS),
+                         "traffic": traffic if args.gemm_mode == 0 else None,
+                         "kernel": ("gemm_f32_kernel<2,2,...> (fused Q/K/V projection)" if args.gemm_mode == 0 else
+                                    f"gemm_split_kernel<{4 - args.gemm_mode},...> (fused Q/K/V projection)"),
+                         "alg_tflops": ach,
                          "launches_timed": q_n, "avg_launch_ms": q_ms / max(q_n, 1),
                          "alg_flops_per_launch": q_fl / max(q_n, 1)},
             "whole_path": {"alg_tflops": impression_flops(w) * value / n_gpus / 1e12,
@@ -396,6 +440,7 @@ def main():
                            "alg_gbs": impression_bytes(w) * value / n_gpus / 1e9,
                            "frac_hbm": impression_bytes(w) * value / n_gpus / 1e9 / HBM_PEAK_GBS},
         }
+        cpu_sample = None
         if n_gpus == 1 and not args.no_cpu_baseline:
             cb, ref = cpu_baseline(w, sd)
             out["cpu_baseline"] = cb
@@ -406,6 +451,7 @@ def main():
                 got = model._forward(b["user_features"]["history"]["title_emb"], b["candidate_features"]["title_emb"])
             err = (got.cpu().double() - ref.double()).abs().max().item() / ref.abs().max().item()
             out["parity_max_rel_err_vs_cpu"] = err
+            cpu_sample = (b, ref)
         else:
             out["cpu_baseline"] = None
         if n_gpus == 1 and not args.no_extra:
@@ -421,6 +467,8 @@ def main():
                 out["extra"]["other_models_fwd_B512_H25"] = other_models_extra(device)
                 out["extra"]["latency_one_impression"] = latency_extra(device)
                 out["extra"]["id_path_B512"] = id_path_extra(device)
+                if args.gemm_mode == 0:
+                    out["extra"]["gemm_modes"] = gemm_modes_extra(model, hist, cand, args.steps, scores, cpu_sample)
             out["extra"]["nrms_train_step_B64"] = train_step_extra(device)
             out["extra"]["standard_train_step_B64"] = train_step_extra(device, model_name="standard")
             out["extra"]["eval_epoch"] = eval_epoch_extra(device)

@@ -59,7 +59,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned BUF_OOB = 0x40000000u;
 
 template <int TM, int TN, bool A_COL, bool B_KN, bool VEC, int PIPE, int BK, bool BUF = false, int MINW = 2>
-__global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_tiles, int n_tiles_seg) {
+__global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_tiles, int n_tiles_seg, int gn) {
   static_assert(!BUF || (!A_COL && !B_KN && VEC), "buffer loads are implemented for the forward layout");
   constexpr int BM = 64 * TM, BN = 64 * TN;
   // k-contiguous LDS tile rows: BK = 32 -> padded to 36 floats (conflict-free ds_read_b128, measured
@@ -86,9 +86,15 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
   const int xcd = bid & 7;
   const int q = nwg >> 3, r = nwg & 7;
   const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  // tile walk: column GROUPS of gn tiles outermost, then the M tiles, then the gn tiles of the group, so the
+  // weight panels an XCD touches over a long stretch (gn * BN * K * 4 <= ~2.5 MB) stay in its 4 MB L2 instead
+  // of streaming through it once per handful of M tiles (Q/K/V projection: 18 column tiles = 7 MB of W).
   const int n_tiles = n_tiles_seg * a.nseg;
-  const int mt = wgid / n_tiles;
-  const int nt = wgid - mt * n_tiles;
+  const int grp = wgid / (gn * m_tiles);
+  const int rem = wgid - grp * gn * m_tiles;
+  const int gw = (n_tiles - grp * gn < gn) ? n_tiles - grp * gn : gn;  // the last group may be narrower
+  const int mt = rem / gw;
+  const int nt = grp * gn + (rem - mt * gw);
   const int seg = nt / n_tiles_seg;
   const int nts = nt - seg * n_tiles_seg;
   const int64_t m0 = (int64_t)mt * BM;
@@ -462,6 +468,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, 
   C[i] = v;
 }
 
+// column tiles per group of the tile walk (see the kernel): as many as keep the group's weight panels within
+// ~2.5 MB, evened out over the groups.  The k-major (backward) layouts keep the plain M-major walk.
+int gemm_group_tiles(int n_tiles, int bn, int64_t K, bool plain) {
+  const char* ge = getenv("XNRS_GEMM_GROUP");  // development knob: tiles per group, 0 = plain walk
+  int64_t gn = (int64_t)(2.5 * 1024 * 1024) / ((int64_t)bn * (K > 0 ? K : 1) * 4);
+  if (ge) gn = atoll(ge);
+  if (plain || gn <= 0 || gn >= n_tiles) return n_tiles;
+  const int groups = (int)((n_tiles + gn - 1) / gn);
+  return (n_tiles + groups - 1) / groups;
+}
+
 template <int TM, int TN, bool A_COL, bool B_KN>
 static hipError_t launch_cfg(const GemmArgs& a, bool vec, int nsplit, hipStream_t stream) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -470,6 +487,7 @@ static hipError_t launch_cfg(const GemmArgs& a, bool vec, int nsplit, hipStream_
   const int64_t grid = m_tiles * n_tiles_seg * a.nseg;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
   const dim3 g((unsigned)grid, (unsigned)nsplit);
+  const int gn = gemm_group_tiles(n_tiles_seg * a.nseg, BN, a.K, A_COL || B_KN);
   // development knobs for in-process A/B runs (tools/bench_gemm.py): XNRS_GEMM_PIPE=1|5|6, XNRS_GEMM_BK=16|32,
   // XNRS_GEMM_BUF=0|1.  Default ("6"): PIPE 5, BK 16, registers capped for 4 workgroups per CU on the main tile.
   const char* pe = getenv("XNRS_GEMM_PIPE");
@@ -481,7 +499,7 @@ static hipError_t launch_cfg(const GemmArgs& a, bool vec, int nsplit, hipStream_
                    (int64_t)a.Nseg * a.ldw * 4 <= (int64_t)BUF_OOB;
 #define XNRS_LAUNCH(VECV, PIPEV, BKV, BUFV, MINWV)                                                                  \
   hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, A_COL, B_KN, VECV, PIPEV, BKV, BUFV, MINWV>), g, dim3(256), 0, stream, a, \
-                     (int)m_tiles, n_tiles_seg)
+                     (int)m_tiles, n_tiles_seg, gn)
   if (!vec) XNRS_LAUNCH(false, 1, 32, false, 2);
   else if constexpr (TM == 2 && TN == 2 && !A_COL && !B_KN) {  // forward main tile: all variants are built
     if (pipe == 1 && buf) XNRS_LAUNCH(true, 1, 32, true, 2);

@@ -48,7 +48,7 @@ __device__ __forceinline__ float lo_f32(unsigned p) { return __uint_as_float(p <
 __device__ __forceinline__ float hi_f32(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
 
 template <int NPL, bool BUF, int MINW>
-__global__ __launch_bounds__(256, MINW) void gemm_split_kernel(GemmArgs a, int m_tiles, int n_tiles_seg) {
+__global__ __launch_bounds__(256, MINW) void gemm_split_kernel(GemmArgs a, int m_tiles, int n_tiles_seg, int gn) {
   constexpr int BM = 128, BN = 128, BK = 16;
   constexpr int NPROD = NPL == 3 ? 6 : 3;
   // product p multiplies plane PA[p] of A with plane PB[p] of B; the biggest term first so the first MFMA
@@ -65,9 +65,12 @@ __global__ __launch_bounds__(256, MINW) void gemm_split_kernel(GemmArgs a, int m
   const int xcd = bid & 7;
   const int q = nwg >> 3, r = nwg & 7;
   const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int n_tiles = n_tiles_seg * a.nseg;
-  const int mt = wgid / n_tiles;
-  const int nt = wgid - mt * n_tiles;
+  const int n_tiles = n_tiles_seg * a.nseg;  // grouped tile walk: see gemm_f32_kernel
+  const int grp = wgid / (gn * m_tiles);
+  const int rem = wgid - grp * gn * m_tiles;
+  const int gw = (n_tiles - grp * gn < gn) ? n_tiles - grp * gn : gn;
+  const int mt = rem / gw;
+  const int nt = grp * gn + (rem - mt * gw);
   const int seg = nt / n_tiles_seg;
   const int nts = nt - seg * n_tiles_seg;
   const int64_t m0 = (int64_t)mt * BM;
@@ -280,11 +283,12 @@ hipError_t launch_gemm_split(const GemmArgs& a, int npl, hipStream_t stream) {
   const int64_t grid = m_tiles * n_tiles_seg * a.nseg;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
   const dim3 g((unsigned)grid, 1);
+  const int gn = gemm_group_tiles(n_tiles_seg * a.nseg, 128, a.K, false);
   const char* ue = getenv("XNRS_GEMM_BUF");
   const bool buf = !(ue && ue[0] == '0') && !a.gather_ids && a.M * a.lda * 4 <= (int64_t)SPLIT_OOB &&
                    (int64_t)a.Nseg * a.ldw * 4 <= (int64_t)SPLIT_OOB;
 #define XNRS_LAUNCH_SPLIT(NPLV, BUFV, MINWV) \
-  hipLaunchKernelGGL((gemm_split_kernel<NPLV, BUFV, MINWV>), g, dim3(256), 0, stream, a, (int)m_tiles, n_tiles_seg)
+  hipLaunchKernelGGL((gemm_split_kernel<NPLV, BUFV, MINWV>), g, dim3(256), 0, stream, a, (int)m_tiles, n_tiles_seg, gn)
   if (npl == 3) {
     if (buf) XNRS_LAUNCH_SPLIT(3, true, 3);
     else XNRS_LAUNCH_SPLIT(3, false, 3);

@@ -43,6 +43,7 @@ struct GemmArgs {
   int64_t slab_stride;  // filled in by the launcher
 };
 int gemm_pick_splits(int64_t M, int64_t N, int64_t K);
+int gemm_group_tiles(int n_tiles, int bn, int64_t K, bool plain);
 size_t gemm_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
 hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t stream);
 // forward-layout GEMM on the bf16 matrix cores by operand splitting (gemm_split.hip); npl = 3 or 2 planes

@@ -339,51 +339,61 @@ __global__ __launch_bounds__(256) void mha_core_lds_kernel(MhaCoreArgs a, int64_
   const float* kbase = a.k + hbase;
   const float* vbase = a.v + hbase;
 
-  if (pvalid) {
-    for (int idx = tp; idx < NSLOT; idx += NTHR) {
-      const int l = idx & 63, blk = idx >> 6;
-      const int kt = blk / NFB, fb = blk - kt * NFB;
-      const int c = l & 15, g = l >> 4;
-      // K fragment: K[16kt + c][16fb + 4g .. +3]
-      const int key = kt * 16 + c, f0 = fb * 16 + 4 * g;
-      f32x4 kv = {0.f, 0.f, 0.f, 0.f};
-      if (key < S && f0 < dk) kv = *reinterpret_cast<const f32x4*>(kbase + key * ld + f0);
-      Ks[gp][idx] = kv;
-      // V fragment: V[16kt + 4g + r][16fb + c], r = 0..3
-      const int dv = fb * 16 + c;
-      f32x4 vv = {0.f, 0.f, 0.f, 0.f};
+  // this wave's query fragments and mask value are fetched FIRST so their latency overlaps the K/V staging
+  // (they do not depend on it)
+  const int QT = (S + 15) >> 4;
+  const int c = lane & 15, g = lane >> 4;
+  const int query = qt * 16 + c;
+  const bool qvalid = pvalid && qt < QT && query < S;
+  const float* qrow = a.q + hbase + (int64_t)(qvalid ? query : 0) * a.ld;
+  f32x4 qf[NFB];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int vkey = kt * 16 + 4 * g + r;
-        if (vkey < S && dv < dk) vv[r] = vbase[vkey * ld + dv];
+  for (int fb = 0; fb < NFB; ++fb) {
+    const int f0 = fb * 16 + 4 * g;
+    qf[fb] = (qvalid && f0 < dk) ? *reinterpret_cast<const f32x4*>(qrow + f0) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int64_t mrow = a.mask ? (a.mask_gather_ids ? (int64_t)a.mask_gather_ids[seq] * S : row0) : 0;
+  const float mq = (a.mask && qvalid) ? a.mask[mrow + query] : 1.f;
+
+  if (pvalid) {
+    // Both operands are READ in row order as 16-byte chunks (192-B runs per head row at d_k = 48) and scattered
+    // into fragment order.  Slot of fragment (tile t, block b, lane (c, g)) = (t*NFB + b)*64 + g*16 + (c ^ x):
+    // the XOR (K: x = 4b + g, V: x = b) spreads the chunk-order writes over the banks and keeps every
+    // fragment read (16 lanes = 16 consecutive c) conflict-free.
+    constexpr int NCH = NFB * 4;  // 16-byte chunks per padded row
+    float* vs = reinterpret_cast<float*>(&Vs[gp][0]);
+    for (int idx = tp; idx < KT * 16 * NCH; idx += NTHR) {
+      const int key = idx / NCH, ch = idx - key * NCH, f0 = ch * 4;
+      const bool ok = key < S && f0 < dk;
+      f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        kv = *reinterpret_cast<const f32x4*>(kbase + key * ld + f0);
+        vv = *reinterpret_cast<const f32x4*>(vbase + key * ld + f0);
       }
-      Vs[gp][idx] = vv;
+      const int kt = key >> 4, kc = key & 15, b = ch >> 2, g4 = ch & 3;
+      // K fragment (kt, fb = b, lane (c = kc, g = g4)) = K[16kt + c][16fb + 4g .. +3]
+      Ks[gp][(kt * NFB + b) * 64 + g4 * 16 + (kc ^ ((4 * b + g4) & 15))] = kv;
+      // V fragment (kt, dt = b, lane (c = 4*g4 + j, g = kc >> 2)) element r = kc & 3  = V[16kt + 4g + r][16dt + c]
+      float* dst = vs + ((kt * NFB + b) * 64 + (kc >> 2) * 16) * 4 + (kc & 3);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dst[((4 * g4 + j) ^ b) * 4] = vv[j];
     }
   }
   __syncthreads();
-  const int QT = (S + 15) >> 4;
   if (!pvalid || qt >= QT) return;
 
-  const int c = lane & 15, g = lane >> 4;
-  const int query = qt * 16 + c;
-  const bool qvalid = query < S;
-  const float* qrow = a.q + hbase + (int64_t)(qvalid ? query : 0) * a.ld;
   f32x4 acc[KT];
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int fb = 0; fb < NFB; ++fb) {
-    const int f0 = fb * 16 + 4 * g;
-    const f32x4 qf = (qvalid && f0 < dk) ? *reinterpret_cast<const f32x4*>(qrow + f0) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
-      const f32x4 kf = Ks[gp][(kt * NFB + fb) * 64 + lane];
+      const f32x4 kf = Ks[gp][(kt * NFB + fb) * 64 + g * 16 + (c ^ ((4 * fb + g) & 15))];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qf[e], acc[kt], 0, 0, 0);
+      for (int e = 0; e < 4; ++e) acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qf[fb][e], acc[kt], 0, 0, 0);
     }
   }
-  const int64_t mrow = a.mask ? (a.mask_gather_ids ? (int64_t)a.mask_gather_ids[seq] * S : row0) : 0;
-  const float mq = (a.mask && qvalid) ? a.mask[mrow + query] : 1.f;
   const float inv_sq = a.scaled ? 1.f / sqrtf((float)dk) : 1.f;
   float mx = -INFINITY;
 #pragma unroll
@@ -434,7 +444,7 @@ __global__ __launch_bounds__(256) void mha_core_lds_kernel(MhaCoreArgs a, int64_
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
-      const f32x4 vf = Vs[gp][(kt * NFB + dt) * 64 + lane];
+      const f32x4 vf = Vs[gp][(kt * NFB + dt) * 64 + g * 16 + (c ^ dt)];
 #pragma unroll
       for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r], acc[kt][r], o, 0, 0, 0);
     }
