@@ -14,13 +14,15 @@ from xnrs_amd import hip, ops  # noqa: E402
 
 dev = torch.device("cuda", 0)
 shapes = [(65500, 2304, 768), (65500, 768, 768), (30720, 960, 320)]
+if os.environ.get("XNRS_BENCH_SHAPES"):  # "M,N,K;M,N,K"
+    shapes = [tuple(int(v) for v in t.split(",")) for t in os.environ["XNRS_BENCH_SHAPES"].split(";")]
 # variants: "name:ENV=v+ENV=v,name2:..."; default compares the plain double-buffered pipeline with the default one
 spec = sys.argv[1] if len(sys.argv) > 1 else "p1k32:XNRS_GEMM_PIPE=1+XNRS_GEMM_BK=32,default:,p5k32:XNRS_GEMM_PIPE=5+XNRS_GEMM_BK=32,p5k16_3wg:XNRS_GEMM_PIPE=5+XNRS_GEMM_BK=16"
 variants = {}
 for item in spec.split(","):
     name, _, envs = item.partition(":")
     variants[name] = dict(e.split("=") for e in envs.split("+") if e)
-ALL_KEYS = ("XNRS_GEMM_PIPE", "XNRS_GEMM_BK", "XNRS_GEMM_BUF", "XNRS_GEMM_GROUP")
+ALL_KEYS = ("XNRS_GEMM_PIPE", "XNRS_GEMM_BK", "XNRS_GEMM_BUF", "XNRS_GEMM_GROUP", "XNRS_GEMM_TILE")
 torch.manual_seed(0)
 for (M, N, K) in shapes:
     x = torch.randn(M, K, device=dev)

@@ -525,7 +525,9 @@ static hipError_t launch_cfg(const GemmArgs& a, bool vec, int nsplit, hipStream_
 template <bool A_COL, bool B_KN>
 static hipError_t launch_layout(const GemmArgs& a, bool vec, int nsplit, hipStream_t stream) {
   // pick the tile with the least estimated time: rounds of co-resident workgroups x padded tile work
-  // (2 workgroups/CU x 256 CUs per round); bigger tiles have slightly better MFMA duty.
+  // (forward variants: 4 workgroups/CU x 256 CUs per round, k-major variants 2/CU); bigger tiles have slightly
+  // better MFMA duty.  Measured with the forced-tile knob: 30 720 x 256 x 300 -> 87 TF at 128x128 (480 of
+  // 1 024 slots filled), 98 TF at 64x64.
   const int cand[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
   const double eff[4] = {1.0, 0.94, 0.94, 0.86};
   int best = 0;
@@ -533,13 +535,16 @@ static hipError_t launch_layout(const GemmArgs& a, bool vec, int nsplit, hipStre
   for (int c = 0; c < 4; ++c) {
     const int64_t bm = 64 * cand[c][0], bn = 64 * cand[c][1];
     const int64_t wgs = ((a.M + bm - 1) / bm) * ((a.Nseg + bn - 1) / bn) * a.nseg * nsplit;
-    const double rounds = (double)((wgs + 511) / 512);
+    const int64_t slots = (A_COL || B_KN) ? 512 : 1024;
+    const double rounds = (double)((wgs + slots - 1) / slots);
     const double t = rounds * (double)(bm * bn) / eff[c];
     if (t < best_t * 0.999) {
       best_t = t;
       best = c;
     }
   }
+  const char* te = getenv("XNRS_GEMM_TILE");  // development knob: force tile candidate 0..3
+  if (te && te[0] >= '0' && te[0] <= '3') best = te[0] - '0';
   switch (best) {
     case 0: return launch_cfg<2, 2, A_COL, B_KN>(a, vec, nsplit, stream);
     case 1: return launch_cfg<2, 1, A_COL, B_KN>(a, vec, nsplit, stream);
