@@ -268,3 +268,31 @@ def test_forward_is_hipgraph_capturable():
         g.replay()
         torch.cuda.synchronize()
     assert torch.equal(out, ref)
+
+
+def test_full_size_properties():
+    """BASELINE configs[2] at full size (B=512, H=50, C=5, S=50, D=768): size-independent properties.
+
+    * impressions are independent: the B=512 step equals, bit for bit, the same impressions scored in ragged
+      sub-batches (different chunking of the 28 160 news, different GEMM tile assignment of every row);
+    * permuting the candidates of an impression permutes its scores;
+    * a slice of the full-size result matches the CPU oracle within the parity bar."""
+    import bench
+    dev = torch.device(DEV)
+    w = dict(bench.WORKLOAD)
+    model, sd = bench.build_model(w, dev)
+    hist, cand = bench.make_inputs(w, dev, seed=5)
+    with torch.no_grad():
+        full = bench.step(model, hist, cand)
+        assert full.shape == (w["B"], w["C"], 1) and torch.isfinite(full).all()
+        parts, b0 = [], 0
+        for nb in (37, 200, 1, 274):
+            parts.append(bench.step(model, tuple(t[b0:b0 + nb] for t in hist), tuple(t[b0:b0 + nb] for t in cand)))
+            b0 += nb
+        assert b0 == w["B"] and torch.equal(torch.cat(parts), full)
+        perm = torch.tensor([3, 0, 4, 1, 2], device=dev)
+        permuted = bench.step(model, hist, tuple(t[:, perm] for t in cand))
+        assert torch.equal(permuted, full[:, perm])
+        sl = slice(100, 104)
+        ref = O.parent_forward(tuple(t[sl].cpu() for t in hist), tuple(t[sl].cpu() for t in cand), sd, w["h"])
+    H.assert_close(full[sl], ref, what="full-size slice vs oracle")
