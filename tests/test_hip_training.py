@@ -77,3 +77,59 @@ def test_training_learns_and_eval_improves(model_name):
     # ReLU'd scores tie at 0 for many negatives (AUC counts ties as 1/2), so the bar is relative
     assert after["auc"] > before["auc"] + 0.15, (before, after)
     assert after["ndcg@10"] > before["ndcg@10"] and after["ctr@1"] > before["ctr@1"] + 0.2, (before, after)
+
+
+def test_one_rank_rccl_train_step_equals_plain_step():
+    """The N>1 train step (xnrs_amd.distributed over backend "nccl" = RCCL) with HIP modules and device tensors.
+    One GPU here, so world_size 1: every collective runs through RCCL on device memory, and the result must
+    equal the plain single-process step bit for bit.  (World size 2 is covered on CPU/gloo by
+    tests/test_distributed_gloo.py; two ranks cannot share one device under RCCL.)"""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    from xnrs_amd import distributed as D
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    c = dict(model="NRMS", E=32, bias=False, h=4, D=32, H=8, S=6)
+    cfg = Cfg(cases.model_cfg(c))
+    cfg["p_dropout"] = 0.0
+    store, beh = synthetic_world(n_news=120, n_sess=64)
+    store, beh = store.to(DEV), beh.to(DEV)
+    sess = torch.arange(48, device=DEV)
+    hist, cand, targets = DeviceBatcher(beh, l_hist=8).train_batch(sess, n_neg=4, seed=3)
+    labels = beh.theme_labels[sess]
+
+    def step(distributed):
+        torch.manual_seed(0)
+        model = make_model(cfg).to(DEV).eval()
+        if distributed:
+            D.broadcast_parameters(model)
+        r, u, _ = model.forward_ids(store.x, store.m, hist, cand, return_embeddings=True)
+        rec = torch.nn.functional.mse_loss(torch.relu(r), targets)
+        if distributed:
+            ue = D.all_gather_rows(u.squeeze(1))
+            lab = D.all_gather_labels(labels)
+            loss = D.global_train_loss(rec, r.shape[0], r.shape[0], contrastive_loss(ue, lab, 0.08), 0.1)
+        else:
+            loss = rec + 0.1 * contrastive_loss(u.squeeze(1), labels, 0.08)
+        loss.backward()
+        if distributed:
+            D.allreduce_gradients(model.parameters())
+        return loss.detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    l0, g0 = step(False)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        l1, g1 = step(True)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(l0, l1) and len(g0) > 0
+    for k, a in g0.items():
+        assert torch.equal(a, g1[k]), k
