@@ -329,6 +329,23 @@ def gemm_modes_extra(model, hist, cand, steps, scores_f32, cpu_sample):
     return out
 
 
+def skip_empty_extra(model, hist, cand, steps, scores_dense):
+    """The same step with TextEncoder.skip_empty: the all-masked history slots (49 % of the history of this
+    synthetic workload, SURVEY.md section 8d: history length ~ U{1..H}) take the constant head(0) vector instead of
+    a full encode.  Exact, but data-dependent work, hence not the headline."""
+    B, H = hist[1].shape[:2]
+    empty = 1.0 - hist[1].reshape(B, H, -1).ne(0).any(dim=2).float().mean().item()
+    model.news_encoder.skip_empty = True
+    try:
+        fn = lambda: step(model, hist, cand)  # noqa: E731
+        dt = timed(fn, steps, 2, False)
+        same = bool(torch.equal(fn(), scores_dense))
+    finally:
+        model.news_encoder.skip_empty = False
+    return dict(empty_history_slots=empty, impressions_per_s=B * steps / dt, ms_per_step=dt / steps * 1e3,
+                equals_dense=same)
+
+
 def latency_extra(device, reps=50):
     """Launch-bound regime: ONE impression (H=25, C=5, S=50, D=768) -- ~15 kernel launches -- eager vs a
     captured hipGraph replay (the C ABI allocates nothing and syncs nothing, so the forward is capturable)."""
@@ -467,6 +484,7 @@ def main():
                 out["extra"]["other_models_fwd_B512_H25"] = other_models_extra(device)
                 out["extra"]["latency_one_impression"] = latency_extra(device)
                 out["extra"]["id_path_B512"] = id_path_extra(device)
+                out["extra"]["skip_empty_history_slots"] = skip_empty_extra(model, hist, cand, args.steps, scores)
                 if args.gemm_mode == 0:
                     out["extra"]["gemm_modes"] = gemm_modes_extra(model, hist, cand, args.steps, scores, cpu_sample)
             out["extra"]["nrms_train_step_B64"] = train_step_extra(device)

@@ -296,3 +296,33 @@ def test_full_size_properties():
         sl = slice(100, 104)
         ref = O.parent_forward(tuple(t[sl].cpu() for t in hist), tuple(t[sl].cpu() for t in cand), sd, w["h"])
     H.assert_close(full[sl], ref, what="full-size slice vs oracle")
+
+
+def test_skip_empty_slots_is_exact():
+    """TextEncoder.skip_empty: all-masked news (empty history slots, whatever their x) take the constant
+    head(0) vector; encoding only the live news must not change a value (benchmark shape, ragged histories)."""
+    import bench
+    dev = torch.device(DEV)
+    w = dict(bench.WORKLOAD, B=48)
+    model, _ = bench.build_model(w, dev)
+    hist, cand = bench.make_inputs(w, dev, seed=9)
+    hx = hist[0].clone()
+    b_e = int((hist[1][:, -1].reshape(w["B"], -1).sum(1) == 0).nonzero()[0])  # an impression whose last slot is empty
+    hx[b_e, -1] = 7.0  # an all-masked slot with NON-zero tokens: still the constant
+    hist = (hx, hist[1])
+    with torch.no_grad():
+        r0, u0, c0 = model._forward(hist, cand, return_embeddings=True)
+        h0, hm0 = model.news_encoder(hist)
+        model.news_encoder.skip_empty = True
+        try:
+            r1, u1, c1 = model._forward(hist, cand, return_embeddings=True)
+            h1, hm1 = model.news_encoder(hist)
+            all_empty = model.news_encoder((torch.ones_like(hx[:2]), torch.zeros_like(hist[1][:2])))  # no live news at all
+            dense_empty = None
+        finally:
+            model.news_encoder.skip_empty = False
+        dense_empty = model.news_encoder((torch.ones_like(hx[:2]), torch.zeros_like(hist[1][:2])))
+    assert (hm0 == 0).any() and (hm0 == 1).any()
+    assert torch.equal(h0, h1) and torch.equal(hm0, hm1)
+    assert torch.equal(r0, r1) and torch.equal(u0, u1) and torch.equal(c0, c1)
+    assert torch.equal(all_empty[0], dense_empty[0]) and torch.equal(all_empty[1], dense_empty[1])

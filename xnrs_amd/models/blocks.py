@@ -91,10 +91,30 @@ class TextEncoder(_Tower):
             self.head = _mlp_head(in_features, out_features, activation, bias)
         self.out_dim = out_features
 
+    # Opt-in (inference): encode only the news that have at least one unmasked token.  An all-masked news (an
+    # empty history slot, dataset.py:82-85) pools to exactly 0 whatever its x is -- every pooling weight is
+    # exp(e)*0 (layers.py:62-65) -- so its vector is the constant head(0), and the row-mask quirk cannot reach
+    # it (all of its query rows are masked).  The non-empty news are gathered by row id inside the first GEMM's
+    # load phase, one empty row rides along to produce the constant, and the vectors are scattered back.
+    # Identical results; data-dependent work, so benchmarks report it separately (it costs one host sync).
+    skip_empty: bool = False
+
     def forward(self, inpt: tuple):
         x, m = self._to_own_device(*inpt)
         b, n, s, d = x.shape
-        y, hm = ops.text_encoder(self.dropout(x.reshape(b * n, s, d)), m.reshape(b * n, s, 1), self)
+        xf, mf = self.dropout(x.reshape(b * n, s, d)), m.reshape(b * n, s, 1)
+        if self.skip_empty and not torch.is_grad_enabled():
+            live = mf.reshape(b * n, s).ne(0).any(dim=1)
+            idx = live.nonzero().squeeze(1)
+            if 0 < idx.numel() < b * n:
+                first_empty = (~live).nonzero()[:1].squeeze(1)
+                ids = torch.cat([idx, first_empty]).to(torch.int32)
+                yv, hv = ops.text_encoder(xf, mf, self, ids=ids)
+                y = yv[-1:].expand(b * n, -1).clone()
+                hm = hv[-1:].expand(b * n).clone()
+                y[idx], hm[idx] = yv[:-1], hv[:-1]
+                return y.reshape(b, n, self.out_dim), hm.reshape(b, n, 1)
+        y, hm = ops.text_encoder(xf, mf, self)
         return y.reshape(b, n, self.out_dim), hm.reshape(b, n, 1)
 
     def forward_ids(self, table_x: torch.Tensor, table_m: torch.Tensor, ids: torch.Tensor, dedup: bool = False):
