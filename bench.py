@@ -329,21 +329,32 @@ def gemm_modes_extra(model, hist, cand, steps, scores_f32, cpu_sample):
     return out
 
 
-def skip_empty_extra(model, hist, cand, steps, scores_dense):
-    """The same step with TextEncoder.skip_empty: the all-masked history slots (49 % of the history of this
-    synthetic workload, SURVEY.md section 8d: history length ~ U{1..H}) take the constant head(0) vector instead of
-    a full encode.  Exact, but data-dependent work, hence not the headline."""
+def padding_free_extra(model, hist, cand, steps, scores_dense):
+    """The same step without the padding work (both exact, both data-dependent, hence not the headline):
+      skip_empty : all-masked news -- the empty history slots, 49 % of this synthetic workload's history
+                   (SURVEY.md section 8d: history length ~ U{1..H}) -- take the constant head(0) vector;
+      unpadded   : masked TOKEN rows (token length ~ U{5..S}: 45 % of the rows) are skipped wherever they cannot
+                   reach the output (Q projection, attention rows, out-projection, fc1, pooling; K/V stay dense)."""
     B, H = hist[1].shape[:2]
-    empty = 1.0 - hist[1].reshape(B, H, -1).ne(0).any(dim=2).float().mean().item()
-    model.news_encoder.skip_empty = True
-    try:
-        fn = lambda: step(model, hist, cand)  # noqa: E731
-        dt = timed(fn, steps, 2, False)
-        same = bool(torch.equal(fn(), scores_dense))
-    finally:
-        model.news_encoder.skip_empty = False
-    return dict(empty_history_slots=empty, impressions_per_s=B * steps / dt, ms_per_step=dt / steps * 1e3,
-                equals_dense=same)
+    enc = model.news_encoder
+    out = {"empty_history_slots": 1.0 - hist[1].reshape(B, H, -1).ne(0).any(dim=2).float().mean().item(),
+           "masked_token_rows_of_live_news": None}
+    live = hist[1].reshape(B * H, -1).ne(0)
+    nz = live.any(dim=1)
+    n_tok = float(nz.sum().item() * live.shape[1] + cand[1].numel())
+    out["masked_token_rows_of_live_news"] = 1.0 - float(live[nz].sum().item() + cand[1].ne(0).sum().item()) / n_tok
+    for name, flags in (("skip_empty", dict(skip_empty=True)), ("unpadded", dict(unpadded=True)),
+                        ("skip_empty+unpadded", dict(skip_empty=True, unpadded=True))):
+        for k, v in flags.items():
+            setattr(enc, k, v)
+        try:
+            fn = lambda: step(model, hist, cand)  # noqa: E731
+            dt = timed(fn, steps, 2, False)
+            same = bool(torch.equal(fn(), scores_dense))
+        finally:
+            enc.skip_empty = enc.unpadded = False
+        out[name] = dict(impressions_per_s=B * steps / dt, ms_per_step=dt / steps * 1e3, equals_dense=same)
+    return out
 
 
 def latency_extra(device, reps=50):
@@ -484,7 +495,7 @@ def main():
                 out["extra"]["other_models_fwd_B512_H25"] = other_models_extra(device)
                 out["extra"]["latency_one_impression"] = latency_extra(device)
                 out["extra"]["id_path_B512"] = id_path_extra(device)
-                out["extra"]["skip_empty_history_slots"] = skip_empty_extra(model, hist, cand, args.steps, scores)
+                out["extra"]["padding_free"] = padding_free_extra(model, hist, cand, args.steps, scores)
                 if args.gemm_mode == 0:
                     out["extra"]["gemm_modes"] = gemm_modes_extra(model, hist, cand, args.steps, scores, cpu_sample)
             out["extra"]["nrms_train_step_B64"] = train_step_extra(device)

@@ -111,6 +111,25 @@ int32_t xnrs_text_encoder_fwd(const float *x, const float *m, const int32_t *ids
                               const xnrs_additive_params *pool, const xnrs_head_params *head, float *y,
                               float *hm, int64_t chunk, void *ws, size_t ws_bytes, void *stream);
 
+/* ---- TextEncoder.forward without the padding work (inference) --------------------------------
+ * Same result as xnrs_text_encoder_fwd for 0/1 masks, computing only what can reach the output
+ * (news_encoding.py:34-60 + layers.py:47-69,120-156): a masked token row has pooling weight exp(e)*0, so its
+ * query projection, attention row, output projection and fc1 row are dead; as a KEY it is alive (the reference
+ * masks query rows only, layers.py:142-144), so K and V are still projected for every row.
+ *   rows    : int32 [n_valid]   source token row (row of x viewed as [*, D]) of every unmasked token, in order
+ *   row_off : int64 [n_news+1]  news n owns the compact rows row_off[n] .. row_off[n+1]; row_off[n_news] = n_valid
+ * x is (n_news,S,D), or the table when ids != NULL (ids: table row of each news, used for K/V; `rows` then holds
+ * table token rows).  att may be NULL (additive-only towers); the pooler is the additive one.  One pass (the
+ * caller bounds n_news per call); hm[n] = (row_off[n+1] > row_off[n]).  Requires S <= 64 and d_k <= 64, d_k % 4 == 0
+ * when att != NULL (XNRS_EUNSUPPORTED otherwise -- use the padded entry point). */
+size_t xnrs_text_encoder_unpadded_workspace_bytes(int64_t n_news, int64_t n_valid, int32_t S, int32_t D, int32_t A,
+                                                  int32_t E, int32_t has_att, int32_t has_head);
+int32_t xnrs_text_encoder_fwd_unpadded(const float *x, const int32_t *ids, int64_t n_news, int32_t S, int32_t D,
+                                       const int32_t *rows, const int64_t *row_off, int64_t n_valid,
+                                       const xnrs_mha_params *att, const xnrs_additive_params *pool,
+                                       const xnrs_head_params *head, float *y, float *hm, void *ws, size_t ws_bytes,
+                                       void *stream);
+
 /* ---- UserEncoder.forward (user_encoding.py:50-81) -------------------------------------------
  * x:(B,H,E), m:(B,H) -> y:(B,E) [, a_out:(B,H) when the pooler is additive and a_out != NULL]. */
 size_t xnrs_user_encoder_workspace_bytes(int64_t B, int32_t H, int32_t E, int32_t A, int32_t has_att,

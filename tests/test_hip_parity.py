@@ -3,6 +3,7 @@ inputs and against the committed golden vectors recorded from the real reference
 
 Tolerance: BASELINE.json north_star -- fp32 scores within 1e-4 relative of the reference CPU path
 (tests/helpers.py RTOL; "relative" = max|d| / max|ref| per tensor)."""
+import numpy as np
 import pytest
 import torch
 
@@ -326,3 +327,50 @@ def test_skip_empty_slots_is_exact():
     assert torch.equal(h0, h1) and torch.equal(hm0, hm1)
     assert torch.equal(r0, r1) and torch.equal(u0, u1) and torch.equal(c0, c1)
     assert torch.equal(all_empty[0], dense_empty[0]) and torch.equal(all_empty[1], dense_empty[1])
+
+
+@pytest.mark.parametrize("tower", ["nrms", "additive_only"])
+def test_unpadded_encoder_matches_padded(tower):
+    """TextEncoder.unpadded (xnrs_text_encoder_fwd_unpadded): only the unmasked token rows are projected to
+    queries / attended / out-projected / pooled; K and V for every row.  Prefix masks (the data's shape,
+    dataset.py:77-85): bitwise equal to the padded kernels.  Masks with holes, fully masked and fully live news,
+    the id-gather path and several passes: within the parity bar (only the pooling normaliser's summation order
+    changes)."""
+    from xnrs_amd import ops
+    S, D, h, E = 50, 192, 4, 64
+    att = layers.MultiHeadAttention(h, D) if tower == "nrms" else None
+    enc, sd = load(news_encoding.TextEncoder(pooler=layers.AdditiveAttention(D, 256), p_dropout=0.0, out_features=E,
+                                             in_features=D, att=att), 131)
+    rng = synth.rng_for(132)
+    n = 300
+    x = torch.from_numpy(rng.standard_normal((n, S, D)).astype("float32")).to(DEV)
+    L = rng.integers(0, S + 1, size=n)
+    L[:3] = (0, S, 1)
+    m = torch.from_numpy((np.arange(S)[None, :] < L[:, None]).astype("float32")).to(DEV)
+    with torch.no_grad():
+        y0, hm0 = ops.text_encoder(x, m, enc)
+        y1, hm1 = ops.text_encoder_unpadded(x, m, enc)
+        assert torch.equal(hm0, hm1) and torch.equal(y0, y1)
+        # several passes + the id-gather (table) path
+        ids = torch.from_numpy(rng.integers(0, n, size=(421,)).astype("int32")).to(DEV)
+        y2, hm2 = ops.text_encoder_forward_unpadded(x, m, enc.att, enc.pooler, enc.head, ids=ids, news_per_pass=100)
+        assert torch.equal(y2, y0[ids.long()]) and torch.equal(hm2, hm0[ids.long()])
+        # masks with holes
+        mh = torch.from_numpy((rng.random((n, S)) < 0.5).astype("float32")).to(DEV)
+        mh[0] = 0
+        y3, hm3 = ops.text_encoder(x, mh, enc)
+        y4, hm4 = ops.text_encoder_unpadded(x, mh, enc)
+        assert torch.equal(hm3, hm4)
+        H.assert_close(y4, y3, tol=1e-6, what="holey masks")
+        # against the CPU oracle as well
+        yo, _ = O.text_encoder(x[:40].cpu().unsqueeze(0), mh[:40].cpu().reshape(1, 40, S, 1), sd, h if att is not None else None)
+        H.assert_close(y4[:40], yo.reshape(40, E), what="unpadded vs oracle")
+        # the module switch, combined with skip_empty
+        enc.unpadded = enc.skip_empty = True
+        y5, hm5 = enc((x.reshape(6, 50, S, D), m.reshape(6, 50, S, 1)))
+        enc.unpadded = enc.skip_empty = False
+        assert torch.equal(y5.reshape(n, E), y0) and torch.equal(hm5.reshape(n), hm0)
+        # a non-binary mask is refused, not mis-computed
+        from xnrs_amd.hip import XnrsHipError
+        with pytest.raises(XnrsHipError):
+            ops.text_encoder_unpadded(x, m * 0.5, enc)

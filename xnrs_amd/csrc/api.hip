@@ -353,6 +353,148 @@ int32_t xnrs_text_encoder_fwd(const float* x, const float* m, const int32_t* ids
   return rc;
 }
 
+// ---- unpadded news encoder (inference): workspace carve, every region 256-B aligned
+namespace {
+struct UnpadPlan {
+  size_t off_kv, off_q, off_o, off_y, off_t, off_p, off_h, total;
+};
+UnpadPlan make_unpad_plan(int64_t n_news, int64_t n_valid, int S, int D, int A, int E, bool att, bool head) {
+  UnpadPlan p{};
+  size_t cur = 0;
+  auto take = [&](size_t floats) {
+    const size_t o = cur;
+    cur += (floats * sizeof(float) + 255) / 256 * 256;
+    return o;
+  };
+  const size_t nv = (size_t)(n_valid > 0 ? n_valid : 1);
+  p.off_kv = att ? take((size_t)n_news * S * 2 * D) : 0;
+  p.off_q = att ? take(nv * D) : 0;
+  p.off_o = att ? take(nv * D) : 0;
+  p.off_y = att ? take(nv * D) : 0;
+  p.off_t = take(nv * A);
+  p.off_p = head ? take((size_t)n_news * D) : 0;
+  p.off_h = head ? take((size_t)n_news * E) : 0;
+  p.total = cur;
+  return p;
+}
+}  // namespace
+
+size_t xnrs_text_encoder_unpadded_workspace_bytes(int64_t n_news, int64_t n_valid, int32_t S, int32_t D, int32_t A,
+                                                  int32_t E, int32_t has_att, int32_t has_head) {
+  return make_unpad_plan(n_news, n_valid, S, D, A, E, has_att != 0, has_head != 0).total;
+}
+
+int32_t xnrs_text_encoder_fwd_unpadded(const float* x, const int32_t* ids, int64_t n_news, int32_t S, int32_t D,
+                                       const int32_t* rows, const int64_t* row_off, int64_t n_valid,
+                                       const xnrs_mha_params* att, const xnrs_additive_params* pool,
+                                       const xnrs_head_params* head, float* y, float* hm, void* ws, size_t ws_bytes,
+                                       void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_news == 0) return XNRS_OK;
+  if (!x || !row_off || !pool || !y || n_news < 0 || n_valid < 0 || S <= 0 || D <= 0 || (n_valid > 0 && !rows))
+    return XNRS_EINVAL;
+  if (S > 512) return XNRS_EUNSUPPORTED;
+  const int A = pool->hidden, E = head ? head->out_features : D;
+  if (att) {
+    if (att->n_heads <= 0 || D % att->n_heads != 0) return XNRS_EHEADS;
+    if (S > 64 || D / att->n_heads > 64 || (D / att->n_heads) % 4 != 0 || D % 4 != 0) return XNRS_EUNSUPPORTED;
+  }
+  const UnpadPlan p = make_unpad_plan(n_news, n_valid, S, D, A, E, att != nullptr, head != nullptr);
+  if (p.total > 0 && (!ws || ws_bytes < p.total)) return XNRS_EWORKSPACE;
+  char* w = static_cast<char*>(ws);
+  float* kv = reinterpret_cast<float*>(w + p.off_kv);
+  float* qc = reinterpret_cast<float*>(w + p.off_q);
+  float* oc = reinterpret_cast<float*>(w + p.off_o);
+  float* yc = reinterpret_cast<float*>(w + p.off_y);
+  float* tc = reinterpret_cast<float*>(w + p.off_t);
+  float* pb = reinterpret_cast<float*>(w + p.off_p);
+  float* hb = reinterpret_cast<float*>(w + p.off_h);
+  const int64_t rows_all = n_news * (int64_t)S;
+
+  const float* vals = x;          // what the pooler weights: compact y rows, or x rows through `rows`
+  const int32_t* val_ids = rows;
+  if (att) {
+    const int dk = D / att->n_heads;
+    {  // K and V of EVERY token row: padded tokens stay keys (QUERY-row mask, layers.py:142-144)
+      GemmArgs g{};
+      g.A = x;
+      g.gather_ids = ids;
+      g.gather_S = S;
+      g.lda = D;
+      g.W[0] = att->wk; g.W[1] = att->wv;
+      g.bias[0] = att->bk; g.bias[1] = att->bv;
+      g.nseg = 2;
+      g.Nseg = D;
+      g.ldw = D;
+      g.C = kv;
+      g.ldc = 2 * (int64_t)D;
+      g.M = rows_all;
+      g.K = D;
+      ProfScope ps(0, 2.0 * rows_all * 2.0 * D * D + 2.0 * n_valid * (double)D * D, stream);
+      XNRS_TRY(launch_gemm_f32(g, stream));
+      // Q of the live rows only (row gather through `rows`)
+      if (n_valid > 0)
+        XNRS_TRY(launch_gemm_f32(gemm1(x, rows, 1, D, att->wq, att->bq, qc, D, n_valid, D, D, XNRS_ACT_NONE), stream));
+    }
+    if (n_valid > 0) {
+      MhaCoreArgs ma{};
+      ma.q = qc;
+      ma.q_off = row_off;
+      ma.ldq = D;
+      ma.k = kv;
+      ma.v = kv + D;
+      ma.ld = 2 * (int64_t)D;
+      ma.seq_stride = (int64_t)S * 2 * D;
+      ma.head_stride = dk;
+      ma.out = oc;
+      ma.ldo = D;
+      ma.n_seq = n_news;
+      ma.S = S;
+      ma.n_heads = att->n_heads;
+      ma.d_k = dk;
+      ma.scaled = att->scaled;
+      {
+        ProfScope ps(1, 4.0 * n_valid * (double)S * D, stream);
+        XNRS_TRY(launch_mha_core(ma, stream));
+      }
+      {
+        ProfScope ps(2, 2.0 * n_valid * (double)D * D, stream);
+        XNRS_TRY(launch_gemm_f32(gemm1(oc, nullptr, 0, D, att->wo, att->bo, yc, D, n_valid, D, D, XNRS_ACT_NONE), stream));
+      }
+    }
+    vals = yc;
+    val_ids = nullptr;
+  }
+  if (n_valid > 0) {
+    ProfScope ps(3, 2.0 * n_valid * (double)D * A, stream);
+    XNRS_TRY(launch_gemm_f32(gemm1(vals, val_ids, 1, D, pool->w1, pool->b1, tc, A, n_valid, A, D, XNRS_ACT_TANH), stream));
+  }
+  AdditivePoolArgs pa{};
+  pa.t = tc;
+  pa.w2 = pool->w2;
+  pa.b2 = pool->b2;
+  pa.x = vals;
+  pa.ldx = D;
+  pa.row_off = row_off;
+  pa.row_ids = val_ids;
+  pa.y = head ? pb : y;
+  pa.hm_out = hm;
+  pa.n_seq = n_news;
+  pa.N = S;
+  pa.D = D;
+  pa.A = A;
+  {
+    ProfScope ps(4, 2.0 * n_valid * (double)(A + D), stream);
+    XNRS_TRY(launch_additive_pool(pa, stream));
+  }
+  if (head) {
+    ProfScope ps(5, 2.0 * n_news * ((double)D * E + (double)E * E), stream);
+    XNRS_TRY(launch_gemm_f32(gemm1(pb, nullptr, 0, D, head->w0, head->b0, hb, E, n_news, E, D, XNRS_ACT_RELU), stream));
+    XNRS_TRY(launch_gemm_f32(gemm1(hb, nullptr, 0, E, head->w2, head->b2, y, E, n_news, E, E, XNRS_ACT_NONE), stream));
+  }
+  return XNRS_OK;
+}
+
 size_t xnrs_user_encoder_workspace_bytes(int64_t B, int32_t H, int32_t E, int32_t A, int32_t has_att, int32_t pool_kind,
                                          int32_t has_head) {
   return make_plan(B, H, E, A, E, has_att != 0, pool_kind == XNRS_POOL_ADDITIVE, has_head != 0, true, 0).total;

@@ -71,6 +71,11 @@ struct MhaCoreArgs {
   float dropout_p;
   uint64_t seed;
   float* stats;  // nullable: per (seq, head, query) softmax row statistics {max, sum} kept for the backward
+  // unpadded queries (nullable): the queries of sequence n are the COMPACT rows q_off[n] .. q_off[n+1] of q (row
+  // stride ldq, head h at column h*d_k) and `out` is compact the same way; every compact query is an unmasked row
+  // (mask is ignored), K and V keep the padded [n_seq*S] addressing.  LDS-staged kernel only (S, d_k <= 64).
+  const int64_t* q_off;
+  int64_t ldq;
 };
 hipError_t launch_mha_core(const MhaCoreArgs& a, hipStream_t stream);
 
@@ -135,6 +140,10 @@ struct AdditivePoolArgs {
   float* hm_out;     // [n_seq] or null : clamp(sum mask,0,1)
   int64_t n_seq;
   int32_t N, D, A;
+  // unpadded rows (nullable): sequence n owns the compact rows row_off[n] .. row_off[n+1] (<= N of them) of t and x
+  // (x_gather_ids unused); every compact row is unmasked, `mask` is ignored and hm_out = (count > 0).
+  const int64_t* row_off;
+  const int32_t* row_ids;  // nullable, with row_off: value row of compact row j is x[row_ids[j]] (t stays compact)
 };
 hipError_t launch_additive_pool(const AdditivePoolArgs& a, hipStream_t stream);
 

@@ -341,19 +341,24 @@ __global__ __launch_bounds__(256) void mha_core_lds_kernel(MhaCoreArgs a, int64_
 
   // this wave's query fragments and mask value are fetched FIRST so their latency overlaps the K/V staging
   // (they do not depend on it)
-  const int QT = (S + 15) >> 4;
+  // unpadded queries: this sequence's live rows are the compact range [q0, q0 + nq) of q / out
+  const int64_t q0 = a.q_off ? a.q_off[seq] : row0;
+  const int nq = a.q_off ? (pvalid ? (int)(a.q_off[seq + 1] - q0) : 0) : S;
+  const int QT = (nq + 15) >> 4;
   const int c = lane & 15, g = lane >> 4;
   const int query = qt * 16 + c;
-  const bool qvalid = pvalid && qt < QT && query < S;
-  const float* qrow = a.q + hbase + (int64_t)(qvalid ? query : 0) * a.ld;
+  const bool qvalid = pvalid && qt < QT && query < nq;
+  const float* qrow = a.q_off ? a.q + (q0 + (qvalid ? query : 0)) * a.ldq + hd * dk
+                              : a.q + hbase + (int64_t)(qvalid ? query : 0) * a.ld;
   f32x4 qf[NFB];
 #pragma unroll
   for (int fb = 0; fb < NFB; ++fb) {
     const int f0 = fb * 16 + 4 * g;
     qf[fb] = (qvalid && f0 < dk) ? *reinterpret_cast<const f32x4*>(qrow + f0) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const int64_t mrow = a.mask ? (a.mask_gather_ids ? (int64_t)a.mask_gather_ids[seq] * S : row0) : 0;
-  const float mq = (a.mask && qvalid) ? a.mask[mrow + query] : 1.f;
+  const bool use_mask = a.mask && !a.q_off;
+  const int64_t mrow = use_mask ? (a.mask_gather_ids ? (int64_t)a.mask_gather_ids[seq] * S : row0) : 0;
+  const float mq = (use_mask && qvalid) ? a.mask[mrow + query] : 1.f;
 
   if (pvalid) {
     // Both operands are READ in row order as 16-byte chunks (192-B runs per head row at d_k = 48) and scattered
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(256) void mha_core_lds_kernel(MhaCoreArgs a, int64_
       for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r], acc[kt][r], o, 0, 0, 0);
     }
     const int dv0 = dt * 16 + 4 * g;
-    if (qvalid && dv0 < dk) *reinterpret_cast<f32x4*>(a.out + (row0 + query) * a.ldo + hoff + dv0) = o;
+    if (qvalid && dv0 < dk) *reinterpret_cast<f32x4*>(a.out + (q0 + query) * a.ldo + hoff + dv0) = o;
   }
 }
 
@@ -498,7 +503,8 @@ hipError_t launch_mha_core(const MhaCoreArgs& a, hipStream_t stream) {
   // three or four query tiles: LDS-staged kernel (one wave per tile, K/V shared through LDS; 0.99 vs 1.06 ms
   // at S=50); one or two tiles: head-per-wave kernel (0.17 vs 0.21 ms at S=30).  XNRS_MHA_LDS=0|1 forces one.
   const char* le = getenv("XNRS_MHA_LDS");
-  const bool use_lds = le ? (le[0] != '0') : (KT >= 3);
+  const bool use_lds = a.q_off ? true : (le ? (le[0] != '0') : (KT >= 3));
+  if (a.q_off && (!fast || a.stats || a.dropout_p > 0.f || a.ldq % 4 != 0)) return hipErrorInvalidValue;
   if (fast && use_lds) {
     switch (KT) {
       case 1: return launch_lds_kt<1, 1>(a, stream);

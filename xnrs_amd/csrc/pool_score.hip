@@ -23,20 +23,25 @@ __global__ __launch_bounds__(256) void additive_pool_kernel(AdditivePoolArgs a) 
   __shared__ float s_red[4];
   const int64_t seq = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int N = a.N, A = a.A, D = a.D;
+  const int A = a.A, D = a.D;
   const int64_t src = a.mask_gather_ids ? (int64_t)a.mask_gather_ids[seq] : seq;  // row block of the mask
   const int64_t srcx = a.x_gather_ids ? (int64_t)a.x_gather_ids[seq] : seq;       // row block of the values
+  // unpadded: the rows of this sequence are a compact range and all of them are live
+  const bool csr = a.row_off != nullptr;
+  const int64_t r0 = csr ? a.row_off[seq] : seq * a.N;
+  const int N = csr ? (int)(a.row_off[seq + 1] - r0) : a.N;
+  const float* mask = csr ? nullptr : a.mask;
 
   // 1. scores: one wave per row, lanes stride over the hidden dimension
   const float b2 = a.b2 ? a.b2[0] : 0.f;
   for (int i = wave; i < N; i += 4) {
-    const float* t = a.t + (seq * N + i) * (int64_t)A;
+    const float* t = a.t + (r0 + i) * (int64_t)A;
     float acc = 0.f;
     for (int k = lane; k < A; k += 64) acc = fmaf(t[k], a.w2[k], acc);
     acc = wave_sum(acc);
     if (lane == 0) {
       float e = expf(acc + b2);
-      if (a.mask) e *= a.mask[src * N + i];
+      if (mask) e *= mask[src * N + i];
       s_w[i] = e;
     }
   }
@@ -45,7 +50,7 @@ __global__ __launch_bounds__(256) void additive_pool_kernel(AdditivePoolArgs a) 
   float part = 0.f, mpart = 0.f;
   for (int i = tid; i < N; i += 256) {
     part += s_w[i];
-    if (a.mask) mpart += a.mask[src * N + i];
+    mpart += mask ? mask[src * N + i] : (csr ? 1.f : 0.f);
   }
   part = wave_sum(part);
   mpart = wave_sum(mpart);
@@ -59,19 +64,24 @@ __global__ __launch_bounds__(256) void additive_pool_kernel(AdditivePoolArgs a) 
     if (tid == 0) a.hm_out[seq] = fminf(fmaxf(s_red[0] + s_red[1] + s_red[2] + s_red[3], 0.f), 1.f);
   }
   if (a.a_out)
-    for (int i = tid; i < N; i += 256) a.a_out[seq * N + i] = s_w[i] / denom;
+    for (int i = tid; i < N; i += 256) a.a_out[r0 + i] = s_w[i] / denom;
   // 3. weighted sum of the value rows: thread per column, rows streamed (coalesced across threads)
-  const float* x = a.x + srcx * N * a.ldx;
+  const float* x = a.x + (csr ? r0 : srcx * N) * a.ldx;
+  const int32_t* rid = (csr && a.row_ids) ? a.row_ids + r0 : nullptr;
   for (int d = tid; d < D; d += 256) {
     float acc = 0.f;
-    for (int i = 0; i < N; ++i) acc = fmaf(s_w[i] / denom, x[(int64_t)i * a.ldx + d], acc);
+    if (rid) {
+      for (int i = 0; i < N; ++i) acc = fmaf(s_w[i] / denom, a.x[(int64_t)rid[i] * a.ldx + d], acc);
+    } else {
+      for (int i = 0; i < N; ++i) acc = fmaf(s_w[i] / denom, x[(int64_t)i * a.ldx + d], acc);
+    }
     a.y[seq * D + d] = acc;
   }
 }
 
 hipError_t launch_additive_pool(const AdditivePoolArgs& a, hipStream_t stream) {
   if (a.n_seq <= 0) return hipSuccess;
-  if (a.N > POOL_MAX_N || a.N <= 0) return hipErrorInvalidValue;
+  if (a.N > POOL_MAX_N || a.N <= 0) return hipErrorInvalidValue;  // with row_off: N = the padded length bounds every count
   hipLaunchKernelGGL(additive_pool_kernel, dim3((unsigned)a.n_seq), dim3(256), 0, stream, a);
   return hipGetLastError();
 }

@@ -25,6 +25,7 @@ SYMBOLS = (
     "xnrs_text_encoder_workspace_bytes", "xnrs_text_encoder_fwd", "xnrs_user_encoder_workspace_bytes",
     "xnrs_user_encoder_fwd", "xnrs_dot_scoring_fwd", "xnrs_profile_enable", "xnrs_profile_read",
     "xnrs_set_gemm_mode", "xnrs_get_gemm_mode",
+    "xnrs_text_encoder_unpadded_workspace_bytes", "xnrs_text_encoder_fwd_unpadded",
     "xnrs_seq_encoder_saved_bytes", "xnrs_seq_encoder_fwd_train", "xnrs_seq_encoder_bwd_workspace_bytes",
     "xnrs_seq_encoder_bwd", "xnrs_linear_bwd_workspace_bytes", "xnrs_linear_bwd",
     "xnrs_embedding_linear_bwd_workspace_bytes", "xnrs_embedding_linear_bwd", "xnrs_dot_scoring_bwd",
@@ -101,6 +102,11 @@ def lib():
     l.xnrs_text_encoder_fwd.restype = i32
     l.xnrs_text_encoder_fwd.argtypes = [p, p, p, i64, i32, i32, C.POINTER(MhaParams), i32, C.POINTER(AdditiveParams),
                                         C.POINTER(HeadParams), p, p, i64, p, sz, p]
+    l.xnrs_text_encoder_unpadded_workspace_bytes.restype = sz
+    l.xnrs_text_encoder_unpadded_workspace_bytes.argtypes = [i64, i64, i32, i32, i32, i32, i32, i32]
+    l.xnrs_text_encoder_fwd_unpadded.restype = i32
+    l.xnrs_text_encoder_fwd_unpadded.argtypes = [p, p, i64, i32, i32, p, p, i64, C.POINTER(MhaParams),
+                                                 C.POINTER(AdditiveParams), C.POINTER(HeadParams), p, p, p, sz, p]
     l.xnrs_user_encoder_workspace_bytes.restype = sz
     l.xnrs_user_encoder_workspace_bytes.argtypes = [i64, i32, i32, i32, i32, i32, i32]
     l.xnrs_user_encoder_fwd.restype = i32

@@ -98,23 +98,30 @@ class TextEncoder(_Tower):
     # load phase, one empty row rides along to produce the constant, and the vectors are scattered back.
     # Identical results; data-dependent work, so benchmarks report it separately (it costs one host sync).
     skip_empty: bool = False
+    # Opt-in (inference, additive pooler, 0/1 masks): additionally skip the masked TOKEN rows wherever they cannot
+    # reach the output (query projection, attention rows, output projection, fc1, pooling); K and V are still
+    # projected for every token because the reference masks query rows only (ops.text_encoder_forward_unpadded).
+    unpadded: bool = False
 
     def forward(self, inpt: tuple):
         x, m = self._to_own_device(*inpt)
         b, n, s, d = x.shape
         xf, mf = self.dropout(x.reshape(b * n, s, d)), m.reshape(b * n, s, 1)
+        encode = ops.text_encoder
+        if self.unpadded and not torch.is_grad_enabled() and hasattr(self.pooler, "fc1"):
+            encode = ops.text_encoder_unpadded
         if self.skip_empty and not torch.is_grad_enabled():
             live = mf.reshape(b * n, s).ne(0).any(dim=1)
             idx = live.nonzero().squeeze(1)
             if 0 < idx.numel() < b * n:
                 first_empty = (~live).nonzero()[:1].squeeze(1)
                 ids = torch.cat([idx, first_empty]).to(torch.int32)
-                yv, hv = ops.text_encoder(xf, mf, self, ids=ids)
+                yv, hv = encode(xf, mf, self, ids=ids)
                 y = yv[-1:].expand(b * n, -1).clone()
                 hm = hv[-1:].expand(b * n).clone()
                 y[idx], hm[idx] = yv[:-1], hv[:-1]
                 return y.reshape(b, n, self.out_dim), hm.reshape(b, n, 1)
-        y, hm = ops.text_encoder(xf, mf, self)
+        y, hm = encode(xf, mf, self)
         return y.reshape(b, n, self.out_dim), hm.reshape(b, n, 1)
 
     def forward_ids(self, table_x: torch.Tensor, table_m: torch.Tensor, ids: torch.Tensor, dedup: bool = False):

@@ -155,6 +155,69 @@ def text_encoder_forward(x: torch.Tensor, m: torch.Tensor, att, pooler, head, id
     return y, hm
 
 
+def text_encoder_forward_unpadded(x: torch.Tensor, m: torch.Tensor, att, pooler, head, ids: Optional[torch.Tensor] = None,
+                                  news_per_pass: int = 8192):
+    """TextEncoder.forward computing only what can reach the output (include/xnrs_hip.h:
+    xnrs_text_encoder_fwd_unpadded): the unmasked token rows are compacted (index bookkeeping with torch, one
+    host sync for the counts), K/V are projected for every row, everything else for the live rows only.
+    Inference, additive pooler, 0/1 masks.  Same signature and results as text_encoder_forward."""
+    x = hip.dev_f32(x, "text encoder input")
+    n_tab, S, D = x.shape
+    m2 = _mask2d(m, n_tab, S, "text encoder mask")
+    if ids is not None:
+        if not ids.is_cuda:
+            raise hip.XnrsHipError("ids must live on the HIP device")
+        ids = ids.to(torch.int32).contiguous()
+        live = m2[ids.long()].ne(0)                      # (n, S) mask of the gathered news
+        base = ids.long().unsqueeze(1) * S               # table token row of (news, 0)
+    else:
+        live = m2.ne(0)
+        base = None
+    n = live.shape[0]
+    pool_kind, pp, keep = _pool_args(pooler)
+    if pool_kind != hip.POOL_ADDITIVE:
+        raise hip.XnrsHipError("the unpadded encoder needs the additive pooler")
+    bad = ((m2 != 0) & (m2 != 1)).any()
+    ap = hp = None
+    if att is not None:
+        ap, k2 = hip.mha_params(att, 0.0, 0)
+        keep += k2
+    if head is not None:
+        hp, k3 = hip.head_params(head)
+        keep += k3
+    A, E = pp.hidden, (hp.out_features if hp is not None else D)
+    y = torch.empty((n, E), dtype=torch.float32, device=x.device)
+    hm = torch.empty((n,), dtype=torch.float32, device=x.device)
+    cnt = live.sum(dim=1)
+    off = torch.zeros(n + 1, dtype=torch.int64, device=x.device)
+    torch.cumsum(cnt, 0, out=off[1:])
+    tok = torch.arange(S, device=x.device).unsqueeze(0)
+    l = hip.lib()
+    step = max(1, int(news_per_pass))
+    bounds = list(range(0, n, step)) + [n]
+    off_host = off[bounds].tolist()                       # the one host sync (also surfaces `bad`)
+    if bool(bad):
+        raise hip.XnrsHipError("the unpadded encoder needs a 0/1 mask")
+    for c0, c1, r0, r1 in zip(bounds[:-1], bounds[1:], off_host[:-1], off_host[1:]):
+        nc, nv = c1 - c0, r1 - r0
+        lv = live[c0:c1]
+        if ids is not None:
+            rows = (base[c0:c1] + tok)[lv].to(torch.int32)             # table token rows of the live tokens
+            xp, idp = x, ids[c0:c1]
+        else:
+            rows = (torch.arange(nc, device=x.device).unsqueeze(1) * S + tok)[lv].to(torch.int32)  # rows inside this pass
+            xp, idp = x[c0:c1], None
+        roff = (off[c0:c1 + 1] - r0).contiguous()
+        nbytes = l.xnrs_text_encoder_unpadded_workspace_bytes(nc, nv, S, D, A, E, int(att is not None), int(head is not None))
+        ws = hip.workspace(x.device, nbytes)
+        hip.check(l.xnrs_text_encoder_fwd_unpadded(hip.ptr(xp), hip.ptr(idp), nc, S, D, hip.ptr(rows), hip.ptr(roff), nv,
+                                                   None if ap is None else C.byref(ap), C.byref(pp),
+                                                   None if hp is None else C.byref(hp), hip.ptr(y[c0:c1]), hip.ptr(hm[c0:c1]),
+                                                   hip.ptr(ws), nbytes, hip.stream_ptr(x.device)),
+                  "xnrs_text_encoder_fwd_unpadded")
+    return y, hm
+
+
 def user_encoder_forward(x: torch.Tensor, m: torch.Tensor, att, pooler, head, return_weights: bool = False,
                          dropout_p: float = 0.0, seed: int = 0):
     """UserEncoder.forward core (user_encoding.py:69-81).  x:(B,H,E), m:(B,H,1) -> (B,1,E) [,(B,H,1)]."""
@@ -260,6 +323,17 @@ def text_encoder(x, m, enc, ids=None, chunk: int = 0):
         from . import autograd
         return autograd.text_encoder(x, m, enc, ids, p, seed)
     return text_encoder_forward(x, m, att, pooler, head, ids=ids, chunk=chunk, dropout_p=p, seed=seed)
+
+
+def text_encoder_unpadded(x, m, enc, ids=None):
+    """Inference-only variant of text_encoder that skips the padding work (text_encoder_forward_unpadded).  Falls
+    back to the padded kernels -- loudly impossible cases aside -- when attention dropout is active (train mode)."""
+    att, pooler, head = enc.att, enc.pooler, getattr(enc, "head", None)
+    _check_att(att)
+    p, _ = _att_dropout(att)
+    if _needs_grad(x, enc) or p > 0.0:
+        return text_encoder(x, m, enc, ids=ids)
+    return text_encoder_forward_unpadded(x, m, att, pooler, head, ids=ids)
 
 
 def user_encoder(x, m, enc, return_weights=False):
