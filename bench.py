@@ -350,10 +350,15 @@ def padding_free_extra(model, hist, cand, steps, scores_dense):
         try:
             fn = lambda: step(model, hist, cand)  # noqa: E731
             dt = timed(fn, steps, 2, False)
-            same = bool(torch.equal(fn(), scores_dense))
+            r = fn()
+            same = bool(torch.equal(r, scores_dense))
+            diff = ((r - scores_dense).abs().max() / scores_dense.abs().max()).item()
         finally:
             enc.skip_empty = enc.unpadded = False
-        out[name] = dict(impressions_per_s=B * steps / dt, ms_per_step=dt / steps * 1e3, equals_dense=same)
+        # (in the split GEMM modes a launch of fewer than 512 tiles runs on the fp32 kernel, so a different pass
+        # size can move a result by fp32 rounding noise; in the default mode the scores are bitwise equal)
+        out[name] = dict(impressions_per_s=B * steps / dt, ms_per_step=dt / steps * 1e3, equals_dense=same,
+                         max_rel_diff_vs_dense=diff)
     return out
 
 

@@ -259,7 +259,9 @@ int32_t xnrs_profile_read(double *ms, int64_t *launches, double *flops);
  *                     workload: same distance to the CPU oracle as mode 0).
  *   XNRS_GEMM_BF16X2  (2) two pieces, three products: ~1e-5 relative per product; an opt-in speed knob.
  * Process-wide; the initial value comes from the environment variable XNRS_GEMM_MODE.  The backward
- * GEMMs always run in mode 0.  Returns the previous mode; values outside 0..2 select 0. */
+ * GEMMs always run in mode 0, and so does a forward launch of fewer than 512 128x128 tiles (the fp32 kernel's
+ * smaller tiles win there): in modes 1/2 a row's result can therefore differ by fp32 rounding noise between
+ * two batch sizes, whereas mode 0 is bitwise independent of the batch.  Returns the previous mode; values outside 0..2 select 0. */
 #define XNRS_GEMM_F32 0
 #define XNRS_GEMM_BF16X3 1
 #define XNRS_GEMM_BF16X2 2
