@@ -266,8 +266,20 @@ def eval_epoch_extra(device, n_news=20000, n_sess=20000):
     res = evaluate(model, store, beh, w["H"], batch=8192)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # the same epoch with the padding-free news encoder (exact; section 10.1 of DESIGN.md)
+    model.news_encoder.unpadded = True
+    try:
+        evaluate(model, store, beh, w["H"], batch=8192)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res_u = evaluate(model, store, beh, w["H"], batch=8192)
+        torch.cuda.synchronize()
+        dt_u = time.perf_counter() - t0
+    finally:
+        model.news_encoder.unpadded = False
     return dict(n_news=n_news, n_impressions=n_sess, candidates=int(beh.pos_off[-1] + beh.neg_off[-1]), seconds=dt,
-                impressions_per_s=n_sess / dt, auc=res["auc"])
+                impressions_per_s=n_sess / dt, auc=res["auc"],
+                unpadded=dict(seconds=dt_u, impressions_per_s=n_sess / dt_u, same_metrics=bool(res_u == res)))
 
 
 def id_path_extra(device, steps=5, warmup=2, n_news=65536):

@@ -368,8 +368,10 @@ def test_unpadded_encoder_matches_padded(tower):
         # the module switch, combined with skip_empty
         enc.unpadded = enc.skip_empty = True
         y5, hm5 = enc((x.reshape(6, 50, S, D), m.reshape(6, 50, S, 1)))
+        y6, hm6 = enc.forward_ids(x, m, ids.reshape(1, -1).long(), dedup=True)  # table path through the same switch
         enc.unpadded = enc.skip_empty = False
         assert torch.equal(y5.reshape(n, E), y0) and torch.equal(hm5.reshape(n), hm0)
+        assert torch.equal(y6[0], y0[ids.long()]) and torch.equal(hm6[0, :, 0], hm0[ids.long()])
         # a non-binary mask is refused, not mis-computed
         from xnrs_amd.hip import XnrsHipError
         with pytest.raises(XnrsHipError):

@@ -103,13 +103,16 @@ class TextEncoder(_Tower):
     # projected for every token because the reference masks query rows only (ops.text_encoder_forward_unpadded).
     unpadded: bool = False
 
+    def _encoder_fn(self):
+        if self.unpadded and not torch.is_grad_enabled() and hasattr(self.pooler, "fc1"):
+            return ops.text_encoder_unpadded
+        return ops.text_encoder
+
     def forward(self, inpt: tuple):
         x, m = self._to_own_device(*inpt)
         b, n, s, d = x.shape
         xf, mf = self.dropout(x.reshape(b * n, s, d)), m.reshape(b * n, s, 1)
-        encode = ops.text_encoder
-        if self.unpadded and not torch.is_grad_enabled() and hasattr(self.pooler, "fc1"):
-            encode = ops.text_encoder_unpadded
+        encode = self._encoder_fn()
         if self.skip_empty and not torch.is_grad_enabled():
             live = mf.reshape(b * n, s).ne(0).any(dim=1)
             idx = live.nonzero().squeeze(1)
@@ -129,12 +132,13 @@ class TextEncoder(_Tower):
         "unique-news dedup per step"); it changes the algorithmic work, so benchmarks report it separately."""
         b, n = ids.shape
         flat = ids.reshape(-1)
+        encode = self._encoder_fn()
         if dedup:
             uniq, inv = torch.unique(flat, return_inverse=True)  # index bookkeeping only
-            y, hm = ops.text_encoder(table_x, table_m, self, ids=uniq)
+            y, hm = encode(table_x, table_m, self, ids=uniq)
             y, hm = y[inv], hm[inv]
         else:
-            y, hm = ops.text_encoder(table_x, table_m, self, ids=flat)
+            y, hm = encode(table_x, table_m, self, ids=flat)
         return y.reshape(b, n, self.out_dim), hm.reshape(b, n, 1)
 
 
