@@ -94,3 +94,20 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("SURVEY", ""), f"{f} mentions the oracle"
+
+
+def test_header_is_plain_c_and_cxx(tmp_path):
+    """include/xnrs_hip.h is the drop-in boundary: it must compile as C99 and as C++ with nothing but the standard
+    headers (no torch / HIP types in the signatures), and a C translation unit that takes the address of every
+    declared entry point must compile against it."""
+    import subprocess
+    syms = header_symbols()
+    src = tmp_path / "use.c"
+    src.write_text('#include "xnrs_hip.h"\n#include <stddef.h>\n'
+                   "const void *xnrs_all_entry_points[] = {\n" + "".join(f"  (const void *){s},\n" for s in syms) + "};\n"
+                   "size_t xnrs_n_entry_points = sizeof(xnrs_all_entry_points) / sizeof(xnrs_all_entry_points[0]);\n")
+    inc = os.path.join(ROOT, "include")
+    for cmd in (["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-Wno-pedantic", "-I", inc, "-c", str(src), "-o", str(tmp_path / "c.o")],
+                ["g++", "-std=c++17", "-Wall", "-Werror", "-I", inc, "-x", "c++", "-c", str(src), "-o", str(tmp_path / "cxx.o")]):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
