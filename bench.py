@@ -233,7 +233,15 @@ def train_step_extra(device, steps=5, warmup=2, model_name="NRMS"):
         opt.step()
         return loss
     dt = timed(fn, steps, warmup, False) / steps
-    return dict(ms=dt * 1e3, impressions_per_s=w["B"] / dt, batch=w["B"], loss_finite=bool(torch.isfinite(fn()).item()))
+    out = dict(ms=dt * 1e3, impressions_per_s=w["B"] / dt, batch=w["B"], loss_finite=bool(torch.isfinite(fn()).item()))
+    # the same step with the empty history slots sharing one encoded representative (exact)
+    model.news_encoder.skip_empty = True
+    try:
+        dt2 = timed(fn, steps, warmup, False) / steps
+        out["skip_empty"] = dict(ms=dt2 * 1e3, impressions_per_s=w["B"] / dt2, loss_finite=bool(torch.isfinite(fn()).item()))
+    finally:
+        model.news_encoder.skip_empty = False
+    return out
 
 
 def eval_epoch_extra(device, n_news=20000, n_sess=20000):

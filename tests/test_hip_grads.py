@@ -239,3 +239,51 @@ def test_fused_infonce_matches_reference_golden_and_oracle():
     x3 = torch.randn(8, 1, 16, device=DEV)
     lab = torch.tensor([0, 1, 0, 1, 2, 2, 0, 1], device=DEV)
     assert torch.equal(contrastive_loss(x3, lab, 0.08), contrastive_loss(x3[:, 0], lab, 0.08))
+
+
+def test_skip_empty_gradients_match_dense():
+    """TextEncoder.skip_empty under autograd: the empty history slots share one encoded representative (it collects
+    their gradient, e.g. towards the head biases); loss and parameter gradients equal the dense step."""
+    import torch.nn.functional as F
+    from tests.golden import cases as cs
+    from xnrs_amd.models import make_model
+
+    class Cfg(dict):
+        __getattr__ = dict.__getitem__
+
+    c = dict(model="NRMS", E=32, bias=True, h=4, D=32, H=10, S=6)
+    torch.manual_seed(3)
+    model = make_model(Cfg(cs.model_cfg(c))).to(DEV).eval()  # eval: no dropout, so both runs are deterministic
+    g = torch.Generator(device=DEV)
+    g.manual_seed(4)
+    B, Hh, C, S, D = 12, 10, 4, 6, 32
+    hx = torch.randn(B, Hh, S, D, device=DEV, generator=g)
+    hm = (torch.rand(B, Hh, S, 1, device=DEV, generator=g) < 0.7).float()
+    hm[:, 6:] = 0          # trailing empty slots ...
+    hx[:, 6:] = 0
+    hx[0, 7] = 3.0         # ... one of them with non-zero tokens
+    cx = torch.randn(B, C, S, D, device=DEV, generator=g)
+    cm = torch.ones(B, C, S, 1, device=DEV)
+    tgt = torch.zeros(B, C, 1, device=DEV)
+    tgt[:, 0] = 1
+
+    def run(flag):
+        model.zero_grad(set_to_none=True)
+        model.news_encoder.skip_empty = flag
+        try:
+            r = model._forward((hx, hm), (cx, cm))
+            loss = F.mse_loss(r, tgt)  # no relu: random-init scores may all be negative
+            loss.backward()
+        finally:
+            model.news_encoder.skip_empty = False
+        return loss.detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    l0, g0 = run(False)
+    l1, g1 = run(True)
+    assert abs(l0.item() - l1.item()) <= 1e-6 * max(1.0, abs(l0.item()))
+    assert g0.keys() == g1.keys() and len(g0) > 10
+    gmax = max(v.abs().max().item() for v in g0.values())
+    assert gmax > 0
+    for k, ref in g0.items():
+        scale = max(ref.abs().max().item(), 1e-3 * gmax)
+        assert (g1[k] - ref).abs().max().item() / scale <= 1e-4, k

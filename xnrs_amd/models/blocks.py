@@ -91,12 +91,13 @@ class TextEncoder(_Tower):
             self.head = _mlp_head(in_features, out_features, activation, bias)
         self.out_dim = out_features
 
-    # Opt-in (inference): encode only the news that have at least one unmasked token.  An all-masked news (an
+    # Opt-in: encode only the news that have at least one unmasked token.  An all-masked news (an
     # empty history slot, dataset.py:82-85) pools to exactly 0 whatever its x is -- every pooling weight is
     # exp(e)*0 (layers.py:62-65) -- so its vector is the constant head(0), and the row-mask quirk cannot reach
     # it (all of its query rows are masked).  The non-empty news are gathered by row id inside the first GEMM's
     # load phase, one empty row rides along to produce the constant, and the vectors are scattered back.
-    # Identical results; data-dependent work, so benchmarks report it separately (it costs one host sync).
+    # Identical results (forward and gradients); data-dependent work, so benchmarks report it separately (it costs
+    # one host sync).
     skip_empty: bool = False
     # Opt-in (inference, additive pooler, 0/1 masks): additionally skip the masked TOKEN rows wherever they cannot
     # reach the output (query projection, attention rows, output projection, fc1, pooling); K and V are still
@@ -113,17 +114,19 @@ class TextEncoder(_Tower):
         b, n, s, d = x.shape
         xf, mf = self.dropout(x.reshape(b * n, s, d)), m.reshape(b * n, s, 1)
         encode = self._encoder_fn()
-        if self.skip_empty and not torch.is_grad_enabled():
+        if self.skip_empty and not (torch.is_grad_enabled() and xf.requires_grad):  # no input gradient through a gather
             live = mf.reshape(b * n, s).ne(0).any(dim=1)
             idx = live.nonzero().squeeze(1)
-            if 0 < idx.numel() < b * n:
+            k = idx.numel()
+            if 0 < k < b * n:
                 first_empty = (~live).nonzero()[:1].squeeze(1)
                 ids = torch.cat([idx, first_empty]).to(torch.int32)
                 yv, hv = encode(xf, mf, self, ids=ids)
-                y = yv[-1:].expand(b * n, -1).clone()
-                hm = hv[-1:].expand(b * n).clone()
-                y[idx], hm[idx] = yv[:-1], hv[:-1]
-                return y.reshape(b, n, self.out_dim), hm.reshape(b, n, 1)
+                # scatter back by indexing (differentiable: in training the empty representative collects the
+                # gradient of every empty slot, e.g. towards the head biases)
+                pos = torch.full((b * n,), k, dtype=torch.int64, device=xf.device)
+                pos[idx] = torch.arange(k, device=xf.device)
+                return yv[pos].reshape(b, n, self.out_dim), hv[pos].reshape(b, n, 1)
         y, hm = encode(xf, mf, self)
         return y.reshape(b, n, self.out_dim), hm.reshape(b, n, 1)
 
