@@ -103,3 +103,63 @@ def test_random_bi_encoder_matches_oracle(seed):
         os.environ.pop("XNRS_GEMM_SPLIT_MIN_TILES", None)
     H.assert_close(c3, cv, what=what + " bf16x3 cand")
     H.assert_close(r3, ref, what=what + " bf16x3 scores")
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_bi_encoder_gradients_match_oracle(seed):
+    """The hand-written backward (xnrs_seq_encoder_bwd and friends) against torch autograd of the CPU oracle on
+    the same random configurations: parameter gradients of both towers and the input gradients d loss / d x that
+    the explainer needs (explain.py:160-166)."""
+    c = _cfg(100 + seed)
+    D, S, A, h = c["D"], min(c["S"], 64), c["A"], c["h"]
+    Eo = c["E"] if c["head_news"] else D
+    hu = next(k for k in (h, 4, 3, 2, 1) if Eo % k == 0)
+    news = news_encoding.TextEncoder(pooler=_pool(c["pool_news"], D, A), p_dropout=0.0, out_features=Eo, in_features=D,
+                                     head=c["head_news"], att=layers.MultiHeadAttention(h, D) if c["att_news"] else None,
+                                     bias=c["bias"])
+    user = user_encoding.UserEncoder(pooler=_pool(c["pool_user"], Eo, A), p_dropout=0.0, emb_dim=Eo,
+                                     att=layers.MultiHeadAttention(hu, Eo) if c["att_user"] else None,
+                                     head=c["head_user"], bias=c["bias"])
+    model = ParentRec(news, user, scoring.DotScoring())
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth.fill_state_dict(shapes, 7100 + seed)
+    model.load_state_dict(sd)
+    model = model.eval().to(DEV)   # eval: dropout off, gradients on
+
+    rng = synth.rng_for(8100 + seed)
+    Hn = max(c["Hn"], 2)
+    n_hist = rng.integers(1, Hn + 1, size=(c["B"],))
+    hx, hm = synth.token_block(rng, c["B"], Hn, S, D, min_len=1, n_valid=n_hist)
+    cx, cm = synth.token_block(rng, c["B"], c["C"], S, D, min_len=1)
+    wgt = torch.from_numpy(rng.standard_normal((c["B"], c["C"], 1)).astype("float32"))
+
+    hxd, cxd = hx.to(DEV).requires_grad_(True), cx.to(DEV).requires_grad_(True)
+    r = model._forward((hxd, hm), (cxd, cm))
+    (r * wgt.to(DEV)).sum().backward()
+
+    osd = {k: v.clone().requires_grad_(not k.endswith("dummy_param")) for k, v in sd.items()}
+    nsd = {k[len("news_encoder."):]: v for k, v in osd.items() if k.startswith("news_encoder.")}
+    usd = {k[len("user_encoder."):]: v for k, v in osd.items() if k.startswith("user_encoder.")}
+    hxo, cxo = hx.clone().requires_grad_(True), cx.clone().requires_grad_(True)
+    hv, hmask = O.text_encoder(hxo, hm, nsd, h if c["att_news"] else None)
+    cv, _ = O.text_encoder(cxo, cm, nsd, h if c["att_news"] else None)
+    ro = O.dot_scoring(O.user_encoder(hv, hmask, usd, hu if c["att_user"] else None), cv)
+    (ro * wgt).sum().backward()
+
+    what = f"seed {seed}: {c}"
+    H.assert_close(r, ro, what=what + " fwd")
+    gmax = max(v.grad.abs().max().item() for v in osd.values() if v.grad is not None)
+    assert gmax > 0
+    H.assert_close(hxd.grad, hxo.grad, 2e-4, what + " d hist x")
+    H.assert_close(cxd.grad, cxo.grad, 2e-4, what + " d cand x")
+    n = 0
+    for k, p in model.named_parameters():
+        ref = osd[k].grad
+        if ref is None:
+            continue
+        assert p.grad is not None, f"{what}: no grad for {k}"
+        scale = max(ref.abs().max().item(), 1e-3 * gmax)
+        e = (p.grad.cpu().double() - ref.double()).abs().max().item() / scale
+        assert e <= 2e-4, f"{what}: {k}: {e:.3e}"
+        n += 1
+    assert n >= 2
