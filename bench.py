@@ -241,6 +241,25 @@ def train_step_extra(device, steps=5, warmup=2, model_name="NRMS"):
         out["skip_empty"] = dict(ms=dt2 * 1e3, impressions_per_s=w["B"] / dt2, loss_finite=bool(torch.isfinite(fn()).item()))
     finally:
         model.news_encoder.skip_empty = False
+
+    # one history encode feeding both the scores and the InfoNCE term (forward(..., return_embeddings=True) instead of
+    # the reference's second encode at training.py:409; in train mode the two uses then share one dropout draw)
+    def fn_shared():
+        opt.zero_grad()
+        r, u, _ = model(batch, return_embeddings=True)
+        loss = torch.nn.functional.mse_loss(torch.relu(r), targets) + 0.1 * infonce(u.squeeze(1), labels, 0.08)
+        loss.backward()
+        opt.step()
+        return loss
+    dt3 = timed(fn_shared, steps, warmup, False) / steps
+    out["shared_history_encode"] = dict(ms=dt3 * 1e3, impressions_per_s=w["B"] / dt3)
+    model.news_encoder.skip_empty = True
+    try:
+        dt4 = timed(fn_shared, steps, warmup, False) / steps
+        out["shared_history_encode+skip_empty"] = dict(ms=dt4 * 1e3, impressions_per_s=w["B"] / dt4,
+                                                       loss_finite=bool(torch.isfinite(fn_shared()).item()))
+    finally:
+        model.news_encoder.skip_empty = False
     return out
 
 
