@@ -209,7 +209,7 @@ def other_models_extra(device, steps=5, warmup=2):
     return out
 
 
-def train_step_extra(device, steps=5, warmup=2, model_name="NRMS"):
+def train_step_extra(device, steps=5, warmup=2, model_name="NRMS", variants=True):
     """The grad step of the reference (training.py:402-431) on the HIP path: NRMS at the shipped
     config (batch 64, H=25, C=5, S=50, D=768, train-mode attention dropout 0.1), forward + relu/MSE +
     lambda*InfoNCE on a second history encode + backward + Adam."""
@@ -234,6 +234,8 @@ def train_step_extra(device, steps=5, warmup=2, model_name="NRMS"):
         return loss
     dt = timed(fn, steps, warmup, False) / steps
     out = dict(ms=dt * 1e3, impressions_per_s=w["B"] / dt, batch=w["B"], loss_finite=bool(torch.isfinite(fn()).item()))
+    if not variants:
+        return out
     # the same step with the empty history slots sharing one encoded representative (exact)
     model.news_encoder.skip_empty = True
     try:

@@ -535,8 +535,10 @@ static hipError_t launch_layout(const GemmArgs& a, bool vec, int nsplit, hipStre
   for (int c = 0; c < 4; ++c) {
     const int64_t bm = 64 * cand[c][0], bn = 64 * cand[c][1];
     const int64_t wgs = ((a.M + bm - 1) / bm) * ((a.Nseg + bn - 1) / bn) * a.nseg * nsplit;
-    const int64_t slots = (A_COL || B_KN) ? 512 : 1024;
-    const double rounds = (double)((wgs + slots - 1) / slots);
+    const double slots = (A_COL || B_KN) ? 512.0 : 1024.0;
+    // fractional rounds above one: workgroups are re-dispatched one by one, so 7.3 rounds of 128x128 tiles do not cost
+    // 8 (whole rounds made the k-major dX GEMMs pick 128x64 tiles: 87 TF)
+    const double rounds = (double)wgs / slots > 1.0 ? (double)wgs / slots : 1.0;
     const double t = rounds * (double)(bm * bn) / eff[c];
     if (t < best_t * 0.999) {
       best_t = t;
