@@ -15,6 +15,8 @@
 //   dkdv  : wave per (seq, head, 16-key tile); keys on the lanes' column index, loops over the query
 //           tiles and keeps dK^T / dV^T of its 16 keys in accumulators, so nothing is summed across
 //           waves.  Pd and dS are directly the B operands of dV^T = dO^T Pd and dK^T = Q^T dS.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace xnrs {
@@ -281,6 +283,182 @@ __global__ __launch_bounds__(256) void mha_dkdv_kernel(MhaBwdArgs a, int KTn, in
   }
 }
 
+// Fused dQ / dK / dV for S <= 64, d_k <= 64 (16-byte aligned): one workgroup per (sequence, head), wave w owns key
+// tile w.  S and dPd are computed ONCE per (query tile, key tile) -- the two-kernel form computes them in the dq
+// AND in the dkdv kernel -- and every operand is staged once:
+//   * the head's Q and dO rows go to LDS as row-major images (row stride 52 floats: the row-fragment read --
+//     lane (c, g) takes 16 B of row c -- and the transposed fragment read -- 4 x ds_read_b32 of rows 4g+r,
+//     column c -- are both conflict-free; 16*NFB + 4 in general), read from global in row order (192-byte runs
+//     at d_k = 48);
+//   * the wave's 16 keys of K (row and transposed fragments) and V (row fragments) stay in registers;
+//   * per query tile: S, dPd (keys on the lanes' column), Pd and dS in registers, dV^T += dO^T Pd and
+//     dK^T += Q^T dS from the transposed LDS reads; dS is transposed through a 1-KB wave-private LDS tile so that
+//     it is the B operand of dQ^T(partial) = K^T dS^T; the four waves' partial dQ tiles meet in LDS and ONE wave
+//     adds them in key-tile order (deterministic, no atomics) and stores the rows.
+// 960 instead of 1 344 MFMAs per (sequence, head) at S = 50, d_k = 48, no scalar gathers from global.
+constexpr int BWD_TLD = 20;  // row stride of the dS transpose tile
+
+template <int NFB>
+__global__ __launch_bounds__(256) void mha_bwd_fused_kernel(MhaBwdArgs a) {
+  // LDS row stride (floats) of the Q / dO / partial-dQ images: 16*NFB + 4 keeps 16 consecutive rows on 16 distinct
+  // 16-byte bank groups (20, 36, 52, 68 floats) and 4 rows apart on banks +16
+  constexpr int BWD_LD = 16 * NFB + 4;
+  __shared__ __attribute__((aligned(16))) float Qs[64 * BWD_LD];
+  __shared__ __attribute__((aligned(16))) float Ds[64 * BWD_LD];
+  __shared__ __attribute__((aligned(16))) float Ts[4][16 * BWD_TLD];
+  __shared__ __attribute__((aligned(16))) float Ps[2][4][16 * BWD_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int64_t pair = blockIdx.x;
+  const int hd = (int)(pair % a.n_heads);
+  const int64_t seq = pair / a.n_heads;
+  const int S = a.S, dk = a.d_k;
+  const int64_t row0 = seq * S;
+  const int hoff = hd * dk;
+  const int QT = (S + 15) >> 4;  // query tiles = key tiles
+  const bool active = wave < QT;
+
+  // ---- stage Q and dO of this head (rows >= S and features >= d_k as zeros)
+  constexpr int NCH = NFB * 4;
+  for (int idx = tid; idx < 64 * NCH; idx += 256) {
+    const int row = idx / NCH, f0 = (idx - row * NCH) * 4;
+    f32x4 qv = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+    if (row < S && f0 < dk) {
+      qv = *reinterpret_cast<const f32x4*>(a.q + (row0 + row) * a.ld + hoff + f0);
+      dv = *reinterpret_cast<const f32x4*>(a.d_o + (row0 + row) * a.lddo + hoff + f0);
+    }
+    *reinterpret_cast<f32x4*>(&Qs[row * BWD_LD + f0]) = qv;
+    *reinterpret_cast<f32x4*>(&Ds[row * BWD_LD + f0]) = dv;
+  }
+  // ---- this wave's key tile in registers
+  const int key = wave * 16 + c;
+  const bool kvalid = active && key < S;
+  f32x4 kf[NFB], vf[NFB], kT[NFB];
+#pragma unroll
+  for (int fb = 0; fb < NFB; ++fb) {
+    const int f0 = fb * 16 + 4 * g;
+    kf[fb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    vf[fb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (kvalid && f0 < dk) {
+      kf[fb] = *reinterpret_cast<const f32x4*>(a.k + (row0 + key) * a.ld + hoff + f0);
+      vf[fb] = *reinterpret_cast<const f32x4*>(a.v + (row0 + key) * a.ld + hoff + f0);
+    }
+    // transposed fragment: element e = K[16w + 4g + e][16fb + c]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int kk = wave * 16 + 4 * g + e, fa = fb * 16 + c;
+      kT[fb][e] = (active && kk < S && fa < dk) ? a.k[(row0 + kk) * a.ld + hoff + fa] : 0.f;
+    }
+  }
+  const float inv_sq = a.scaled ? 1.f / sqrtf((float)dk) : 1.f;
+  const float keep = 1.f - a.dropout_p;
+  const int64_t mrow = a.mask ? (a.mask_gather_ids ? (int64_t)a.mask_gather_ids[seq] * S : row0) : 0;
+  const int64_t sbase = (seq * a.n_heads + hd) * (int64_t)S;
+  f32x4 dkT[NFB], dvT[NFB];
+#pragma unroll
+  for (int t = 0; t < NFB; ++t) {
+    dkT[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dvT[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+
+  for (int qt = 0; qt < QT; ++qt) {
+    if (active) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int fb = 0; fb < NFB; ++fb) {
+        const f32x4 qf = *reinterpret_cast<const f32x4*>(&Qs[(qt * 16 + c) * BWD_LD + fb * 16 + 4 * g]);
+        const f32x4 df = *reinterpret_cast<const f32x4*>(&Ds[(qt * 16 + c) * BWD_LD + fb * 16 + 4 * g]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[e], kf[fb][e], s, 0, 0, 0);    // S[query 4g+r][key c]
+          dp = __builtin_amdgcn_mfma_f32_16x16x4f32(df[e], vf[fb][e], dp, 0, 0, 0);  // dPd[query 4g+r][key c]
+        }
+      }
+      f32x4 pd, ds;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int query = qt * 16 + 4 * g + r;
+        float pdv = 0.f, dsv = 0.f;
+        if (query < S && kvalid) {
+          const float mq = a.mask ? a.mask[mrow + query] : 1.f;
+          const float mx = a.stats[2 * (sbase + query)];
+          const float sum = a.stats[2 * (sbase + query) + 1];
+          const float delta = a.delta[sbase + query];
+          float sv = s[r] * inv_sq;
+          if (mq == 0.f) sv = -1e9f;
+          const float p = attn_exp(sv - mx) * (1.f / sum);
+          float dpv = dp[r];
+          pdv = p;
+          if (a.dropout_p > 0.f) {
+            const uint64_t idx = ((uint64_t)(seq * a.n_heads + hd) * S + (uint64_t)query) * S + (uint64_t)key;
+            const bool kp = uniform01(a.seed, idx) < keep;
+            pdv = kp ? p / keep : 0.f;
+            dpv = kp ? dpv / keep : 0.f;
+          }
+          if (mq != 0.f) dsv = p * (dpv - delta) * inv_sq;
+        }
+        pd[r] = pdv;
+        ds[r] = dsv;
+      }
+      // dV^T[dv][key] += dO^T[dv][query] Pd[query][key];  dK^T[f][key] += Q^T[f][query] dS[query][key]
+#pragma unroll
+      for (int t = 0; t < NFB; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float dd = Ds[(qt * 16 + 4 * g + r) * BWD_LD + t * 16 + c];
+          const float qq = Qs[(qt * 16 + 4 * g + r) * BWD_LD + t * 16 + c];
+          dvT[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(dd, pd[r], dvT[t], 0, 0, 0);
+          dkT[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qq, ds[r], dkT[t], 0, 0, 0);
+        }
+      }
+      // dS^T through the wave-private tile: written [query 4g+r][key c], read back [query c][keys 4g .. 4g+3]
+      float* T = Ts[wave];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T[(4 * g + r) * BWD_TLD + c] = ds[r];
+      const f32x4 dsT = *reinterpret_cast<const f32x4*>(&T[c * BWD_TLD + 4 * g]);
+      // partial dQ^T[f][query] = K^T[f][key] dS^T[key][query] over this wave's 16 keys
+      float* P = Ps[qt & 1][wave];
+#pragma unroll
+      for (int t = 0; t < NFB; ++t) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o = __builtin_amdgcn_mfma_f32_16x16x4f32(kT[t][e], dsT[e], o, 0, 0, 0);
+        *reinterpret_cast<f32x4*>(&P[c * BWD_LD + t * 16 + 4 * g]) = o;  // query c, features 16t+4g .. +3
+      }
+    }
+    __syncthreads();
+    if (wave == (qt & 3)) {
+      // sum the key tiles' partials in order and store the 16 query rows (row-order 16-byte chunks)
+      for (int idx = lane; idx < 16 * NCH; idx += 64) {
+        const int qr = idx / NCH, f0 = (idx - qr * NCH) * 4;
+        const int query = qt * 16 + qr;
+        if (query < S && f0 < dk) {
+          f32x4 acc = *reinterpret_cast<const f32x4*>(&Ps[qt & 1][0][qr * BWD_LD + f0]);
+          for (int w2 = 1; w2 < QT; ++w2) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&Ps[qt & 1][w2][qr * BWD_LD + f0]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += v[e];
+          }
+          *reinterpret_cast<f32x4*>(a.dq + (row0 + query) * a.ldd + hoff + f0) = acc;
+        }
+      }
+    }
+  }
+  if (kvalid) {
+    float* dkrow = a.dk + (row0 + key) * a.ldd + hoff;
+    float* dvrow = a.dv + (row0 + key) * a.ldd + hoff;
+#pragma unroll
+    for (int t = 0; t < NFB; ++t) {
+      const int f0 = t * 16 + 4 * g;
+      if (f0 < dk) {
+        *reinterpret_cast<f32x4*>(dkrow + f0) = dkT[t];
+        *reinterpret_cast<f32x4*>(dvrow + f0) = dvT[t];
+      }
+    }
+  }
+}
+
 template <int KT>
 static hipError_t launch_dq(const MhaBwdArgs& a, bool vec, hipStream_t stream) {
   const int QT = (a.S + 15) / 16;
@@ -304,6 +482,19 @@ hipError_t launch_mha_bwd(const MhaBwdArgs& a, hipStream_t stream) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const int KT = (a.S + 15) / 16;
+  const char* fe = getenv("XNRS_MHA_BWD_FUSED");  // development knob for A/B runs; default on
+  if (vec && a.S <= 64 && a.d_k <= 64 && !(fe && fe[0] == '0')) {
+    const int64_t n_pairs = a.n_seq * a.n_heads;
+    if (n_pairs > 0x7fffffffLL) return hipErrorInvalidValue;
+    const dim3 fgrid((unsigned)n_pairs);
+    switch ((a.d_k + 15) / 16) {
+      case 1: hipLaunchKernelGGL((mha_bwd_fused_kernel<1>), fgrid, dim3(256), 0, stream, a); break;
+      case 2: hipLaunchKernelGGL((mha_bwd_fused_kernel<2>), fgrid, dim3(256), 0, stream, a); break;
+      case 3: hipLaunchKernelGGL((mha_bwd_fused_kernel<3>), fgrid, dim3(256), 0, stream, a); break;
+      default: hipLaunchKernelGGL((mha_bwd_fused_kernel<4>), fgrid, dim3(256), 0, stream, a); break;
+    }
+    return hipGetLastError();
+  }
   switch (KT) {
     case 1: e = launch_dq<1>(a, vec, stream); break;
     case 2: e = launch_dq<2>(a, vec, stream); break;
