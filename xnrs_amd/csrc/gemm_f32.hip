@@ -458,6 +458,31 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
   }
 }
 
+// Wt[c][r] = W[r][c]: 32x32 tiles through LDS (padded rows), both sides coalesced
+__global__ __launch_bounds__(256) void transpose_kernel(const float* W, float* Wt, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    if (r < rows && c < cols) tile[ty + 8 * i][tx] = W[(int64_t)r * cols + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (r < rows && c < cols) Wt[(int64_t)c * rows + r] = tile[tx][ty + 8 * i];
+  }
+}
+
+hipError_t launch_transpose(const float* W, float* Wt, int rows, int cols, hipStream_t stream) {
+  if (rows <= 0 || cols <= 0) return hipSuccess;
+  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32)), dim3(256), 0, stream, W,
+                     Wt, rows, cols);
+  return hipGetLastError();
+}
+
 // C (+)= sum_s slabs[s]  (fixed order -> bitwise reproducible)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, int64_t slab_stride, int nsplit, float* C,
                                                              int64_t n, int accumulate) {

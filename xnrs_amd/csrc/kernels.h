@@ -42,6 +42,8 @@ struct GemmArgs {
   int64_t k_per_split;  // filled in by the launcher
   int64_t slab_stride;  // filled in by the launcher
 };
+// Wt[c][r] = W[r][c] for a small row-major matrix W[rows][cols] (weights: a few MB)
+hipError_t launch_transpose(const float* W, float* Wt, int rows, int cols, hipStream_t stream);
 int gemm_pick_splits(int64_t M, int64_t N, int64_t K);
 int gemm_group_tiles(int n_tiles, int bn, int64_t K, bool plain);
 size_t gemm_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
