@@ -297,6 +297,9 @@ __global__ __launch_bounds__(256) void mha_dkdv_kernel(MhaBwdArgs a, int KTn, in
 //     adds them in key-tile order (deterministic, no atomics) and stores the rows.
 // 960 instead of 1 344 MFMAs per (sequence, head) at S = 50, d_k = 48, no scalar gathers from global.
 constexpr int BWD_TLD = 20;  // row stride of the dS transpose tile
+#ifndef BWD_PBUF
+#define BWD_PBUF 1  // partial-dQ buffers: 1 (+ one more barrier per query tile, 45 KB -> 3 workgroups/CU) or 2 (58 KB -> 2/CU)
+#endif
 
 template <int NFB>
 __global__ __launch_bounds__(256) void mha_bwd_fused_kernel(MhaBwdArgs a) {
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(256) void mha_bwd_fused_kernel(MhaBwdArgs a) {
   __shared__ __attribute__((aligned(16))) float Qs[64 * BWD_LD];
   __shared__ __attribute__((aligned(16))) float Ds[64 * BWD_LD];
   __shared__ __attribute__((aligned(16))) float Ts[4][16 * BWD_TLD];
-  __shared__ __attribute__((aligned(16))) float Ps[2][4][16 * BWD_LD];
+  __shared__ __attribute__((aligned(16))) float Ps[BWD_PBUF][4][16 * BWD_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int64_t pair = blockIdx.x;
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(256) void mha_bwd_fused_kernel(MhaBwdArgs a) {
       for (int r = 0; r < 4; ++r) T[(4 * g + r) * BWD_TLD + c] = ds[r];
       const f32x4 dsT = *reinterpret_cast<const f32x4*>(&T[c * BWD_TLD + 4 * g]);
       // partial dQ^T[f][query] = K^T[f][key] dS^T[key][query] over this wave's 16 keys
-      float* P = Ps[qt & 1][wave];
+      float* P = Ps[qt & (BWD_PBUF - 1)][wave];
 #pragma unroll
       for (int t = 0; t < NFB; ++t) {
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
@@ -434,9 +437,9 @@ __global__ __launch_bounds__(256) void mha_bwd_fused_kernel(MhaBwdArgs a) {
         const int qr = idx / NCH, f0 = (idx - qr * NCH) * 4;
         const int query = qt * 16 + qr;
         if (query < S && f0 < dk) {
-          f32x4 acc = *reinterpret_cast<const f32x4*>(&Ps[qt & 1][0][qr * BWD_LD + f0]);
+          f32x4 acc = *reinterpret_cast<const f32x4*>(&Ps[qt & (BWD_PBUF - 1)][0][qr * BWD_LD + f0]);
           for (int w2 = 1; w2 < QT; ++w2) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(&Ps[qt & 1][w2][qr * BWD_LD + f0]);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&Ps[qt & (BWD_PBUF - 1)][w2][qr * BWD_LD + f0]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[e] += v[e];
           }
@@ -444,6 +447,7 @@ __global__ __launch_bounds__(256) void mha_bwd_fused_kernel(MhaBwdArgs a) {
         }
       }
     }
+    if (BWD_PBUF == 1) __syncthreads();  // the single partial buffer is rewritten by the next query tile
   }
   if (kvalid) {
     float* dkrow = a.dk + (row0 + key) * a.ldd + hoff;
