@@ -258,10 +258,12 @@ int32_t xnrs_profile_read(double *ms, int64_t *launches, double *flops);
  *                     <= 2^-26 |a||b| per product, i.e. below one fp32 rounding (measured on the full
  *                     workload: same distance to the CPU oracle as mode 0).
  *   XNRS_GEMM_BF16X2  (2) two pieces, three products: ~1e-5 relative per product; an opt-in speed knob.
- * Process-wide; the initial value comes from the environment variable XNRS_GEMM_MODE.  The backward
- * GEMMs always run in mode 0, and so does a forward launch of fewer than 512 128x128 tiles (the fp32 kernel's
- * smaller tiles win there): in modes 1/2 a row's result can therefore differ by fp32 rounding noise between
- * two batch sizes, whereas mode 0 is bitwise independent of the batch.  Returns the previous mode; values outside 0..2 select 0. */
+ * Process-wide; the initial value comes from the environment variable XNRS_GEMM_MODE.  It covers every GEMM
+ * that runs on the forward-layout kernel: the nn.Linear forwards and the input-gradient products dX = dY . W of
+ * the backward (computed against a transposed weight copy); the weight-gradient products dW = dY^T . X always
+ * run in mode 0, and so does any launch of fewer than 512 128x128 tiles (the fp32 kernel's smaller tiles win
+ * there): in modes 1/2 a row's result can therefore differ by fp32 rounding noise between two batch sizes,
+ * whereas mode 0 is bitwise independent of the batch.  Returns the previous mode; values outside 0..2 select 0. */
 #define XNRS_GEMM_F32 0
 #define XNRS_GEMM_BF16X3 1
 #define XNRS_GEMM_BF16X2 2
