@@ -157,3 +157,41 @@ def test_benchmark_shape_scores_under_split(split_mode):
         r2 = bench.step(model, hist, cand)
     H.assert_close(r1, r0, tol=5e-6, what="bf16x3 vs fp32 MFMA")
     H.assert_close(r2, r0, tol=1e-4, what="bf16x2 vs fp32 MFMA")
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_gradients_under_split_modes(split_mode, mode):
+    """The split modes also cover the backward's dX = dY . W products (they run on the forward-layout kernel against a
+    transposed weight copy): parameter and input gradients of a bi-encoder against torch autograd through the oracle."""
+    from oracle import xnrs_oracle as O
+    c = dict(model="NRMS", E=64, bias=True, h=4, D=64, H=6, S=20)
+    model = make_model(Cfg(cases.model_cfg(c)))
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth.fill_state_dict(shapes, 900)
+    model.load_state_dict(sd)
+    model = model.eval().to(DEV)
+    rng = synth.rng_for(901)
+    # enough rows for the transposed-weight path (>= 4096 token rows per encode)
+    hx, hm = synth.token_block(rng, 40, 6, 20, 64, min_len=2)
+    cx, cm = synth.token_block(rng, 40, 3, 20, 64, min_len=2)
+    wgt = torch.from_numpy(rng.standard_normal((40, 3, 1)).astype("float32"))
+    split_mode(mode)
+    hxd, cxd = hx.to(DEV).requires_grad_(True), cx.to(DEV).requires_grad_(True)
+    r = model._forward((hxd, hm), (cxd, cm))
+    (r * wgt.to(DEV)).sum().backward()
+    osd = {k: v.clone().requires_grad_(not k.endswith("dummy_param")) for k, v in sd.items()}
+    hxo, cxo = hx.clone().requires_grad_(True), cx.clone().requires_grad_(True)
+    ro = O.parent_forward((hxo, hm), (cxo, cm), osd, c["h"])
+    (ro * wgt).sum().backward()
+    tol = 2e-4 if mode == 1 else 1e-3
+    H.assert_close(r, ro, what="fwd")
+    H.assert_close(hxd.grad, hxo.grad, tol, "d hist x")
+    H.assert_close(cxd.grad, cxo.grad, tol, "d cand x")
+    gmax = max(v.grad.abs().max().item() for v in osd.values() if v.grad is not None)
+    for k, p in model.named_parameters():
+        ref = osd[k].grad
+        if ref is None:
+            continue
+        scale = max(ref.abs().max().item(), 1e-3 * gmax)
+        e = (p.grad.cpu().double() - ref.double()).abs().max().item() / scale
+        assert e <= tol, f"{k}: {e:.3e}"
