@@ -179,6 +179,19 @@ int32_t xnrs_seq_encoder_bwd(const float *x, const float *m, const int32_t *ids,
                              const xnrs_head_params *head, const void *saved, size_t saved_bytes, const float *dy,
                              float *dx, const xnrs_mha_grads *g_att, const xnrs_additive_grads *g_pool,
                              const xnrs_head_grads *g_head, void *ws, size_t ws_bytes, void *stream);
+/* The same backward over the unmasked token rows only (optional speed-up of the grad step; identical gradients up to
+ * summation order).  A masked token row has pooling weight exp(e)*0, so every gradient that flows through it is
+ * exactly zero; with live_rows (int32 [n_live]: indices of the unmasked rows in the padded [n_seq*L] row space, in
+ * order) the row-parallel products of the attention tower -- fc1, output projection, Q projection -- run over those
+ * rows in place; K / V gradients stay dense (padded tokens are keys, layers.py:142-144).  live_src_rows: the rows of
+ * the live tokens in x when ids != NULL (table rows), NULL otherwise.  Used only with attention + additive pooling
+ * + a mask; ignored (= xnrs_seq_encoder_bwd) otherwise. */
+int32_t xnrs_seq_encoder_bwd_live(const float *x, const float *m, const int32_t *ids, int64_t n_seq, int32_t L, int32_t D,
+                                  const xnrs_mha_params *att, int32_t pool_kind, const xnrs_additive_params *pool,
+                                  const xnrs_head_params *head, const void *saved, size_t saved_bytes, const float *dy,
+                                  float *dx, const xnrs_mha_grads *g_att, const xnrs_additive_grads *g_pool,
+                                  const xnrs_head_grads *g_head, const int32_t *live_rows,
+                                  const int32_t *live_src_rows, int64_t n_live, void *ws, size_t ws_bytes, void *stream);
 
 /* autograd of nn.Linear (xnrs_linear_fwd): dx = dy.W (nullable), dw = dy^T.x, db = colsum(dy) (nullable).
  * gather_ids as in the forward (then dx must be NULL). */

@@ -287,3 +287,54 @@ def test_skip_empty_gradients_match_dense():
     for k, ref in g0.items():
         scale = max(ref.abs().max().item(), 1e-3 * gmax)
         assert (g1[k] - ref).abs().max().item() / scale <= 1e-4, k
+
+
+@pytest.mark.parametrize("with_ids", [False, True])
+def test_backward_over_live_rows_matches_dense_backward(with_ids):
+    """xnrs_seq_encoder_bwd_live (the row-parallel backward products over the unmasked token rows only) against the
+    dense backward and against oracle autograd: parameter gradients of a TextEncoder with attention, masks with
+    holes and fully masked news, with and without the id-gather (table) path, and the input gradient."""
+    from xnrs_amd import autograd as AG
+    S, D, h, E = 24, 64, 4, 32
+    enc, sd = load(news_encoding.TextEncoder(pooler=layers.AdditiveAttention(D, 48), p_dropout=0.0, out_features=E,
+                                             in_features=D, att=layers.MultiHeadAttention(h, D)), 171)
+    rng = synth.rng_for(172)
+    n_tab = 260
+    x = torch.from_numpy(rng.standard_normal((n_tab, S, D)).astype("float32"))
+    m = torch.from_numpy((rng.random((n_tab, S)) < 0.55).astype("float32"))
+    m[:5] = 0
+    w = torch.from_numpy(rng.standard_normal((n_tab if not with_ids else 300, E)).astype("float32"))
+    ids = torch.from_numpy(rng.integers(0, n_tab, size=(300,)).astype("int64")) if with_ids else None
+
+    def run(live):
+        AG.LIVE_ROWS = live
+        try:
+            enc.zero_grad(set_to_none=True)
+            xd = x.to(DEV).requires_grad_(not with_ids)
+            if with_ids:
+                y, _ = enc.forward_ids(xd, m.to(DEV), ids.to(DEV).reshape(1, -1))
+                y = y[0]
+            else:
+                y, _ = enc((xd.unsqueeze(0), m.to(DEV).reshape(1, n_tab, S, 1)))
+                y = y[0]
+            (y * w.to(DEV)).sum().backward()
+        finally:
+            AG.LIVE_ROWS = True
+        return y.detach(), {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None}, xd.grad
+
+    y0, g0, dx0 = run(False)
+    y1, g1, dx1 = run(True)
+    assert torch.equal(y0, y1) and g0.keys() == g1.keys()
+    gmax = max(v.abs().max().item() for v in g0.values())
+    for k in g0:
+        scale = max(g0[k].abs().max().item(), 1e-3 * gmax)
+        assert (g1[k] - g0[k]).abs().max().item() / scale <= 2e-5, k
+    if not with_ids:
+        H.assert_close(dx1, dx0, 2e-5, "dx live vs dense")
+        # and against torch autograd through the oracle
+        osd = oracle_sd(sd)
+        xo = x.clone().requires_grad_(True)
+        yo, _ = O.text_encoder(xo.unsqueeze(0), m.reshape(1, n_tab, S, 1), osd, h)
+        (yo[0] * w).sum().backward()
+        H.assert_close(dx1, xo.grad, GTOL, "dx vs oracle")
+        assert check_param_grads(enc, osd) >= 12

@@ -610,9 +610,12 @@ BwdPlan make_bwd_plan(int64_t n_seq, int L, int D, int A, int E, int n_heads, bo
   return p;
 }
 
-// dW[N,K] = dY^T[N,M] . X[M,K]   (A k-major = dY, B k-major = X), split-K over the M rows
+// dW[N,K] = dY^T[N,M] . X[M,K]   (A k-major = dY, B k-major = X), split-K over the M rows.
+// live (optional): contract over the n_live rows live_dy[j] of dY and live_x[j] of X only (the other rows of dY are
+// known to be zero: masked token rows in the backward).
 hipError_t gemm_dw(const float* dY, int64_t lddy, const float* X, const int32_t* x_ids, int x_S, int64_t ldx, float* dW,
-                   int64_t M, int N, int K, float* slabs, hipStream_t stream) {
+                   int64_t M, int N, int K, float* slabs, hipStream_t stream, const int32_t* live_dy = nullptr,
+                   const int32_t* live_x = nullptr, int64_t n_live = 0) {
   GemmArgs g{};
   g.A = dY;
   g.a_col = 1;
@@ -621,6 +624,14 @@ hipError_t gemm_dw(const float* dY, int64_t lddy, const float* X, const int32_t*
   g.b_kn = 1;
   g.b_gather_ids = x_ids;
   g.b_gather_S = x_S;
+  if (live_dy) {
+    g.gather_ids = live_dy;
+    g.gather_S = 1;
+    g.b_gather_ids = live_x;
+    g.b_gather_S = 1;
+    M = n_live;
+    if (M <= 0) return hipMemsetAsync(dW, 0, (size_t)N * K * sizeof(float), stream);
+  }
   g.ldw = ldx;
   g.nseg = 1;
   g.Nseg = K;
@@ -642,10 +653,17 @@ hipError_t gemm_dw(const float* dY, int64_t lddy, const float* X, const int32_t*
 // CU: ~133 TF -- instead of the k-major variant (87 TF on the 80 000-row dX GEMMs of the NRMS train step).
 hipError_t gemm_dx(const float* dY, int64_t lddy, const float* W, float* dX, int64_t lddx, int64_t M, int N, int K,
                    const float* aux, int64_t ldaux, int aux_mode, int accumulate, hipStream_t stream,
-                   float* wt_scratch = nullptr) {
+                   float* wt_scratch = nullptr, const int32_t* live = nullptr, int64_t n_live = 0) {
   GemmArgs g{};
   g.A = dY;
   g.lda = lddy;
+  if (live) {  // rows live[j] of dY and dX only, in place (the other rows of dY are zero; dX's are left as they are)
+    if (n_live <= 0) return hipSuccess;
+    g.gather_ids = live;
+    g.gather_S = 1;
+    g.c_scatter = 1;
+    M = n_live;
+  }
   g.nseg = 1;
   g.Nseg = K;
   g.C = dX;
@@ -701,6 +719,16 @@ int32_t xnrs_seq_encoder_bwd(const float* x, const float* m, const int32_t* ids,
                              const xnrs_head_params* head, const void* saved, size_t saved_bytes, const float* dy, float* dx,
                              const xnrs_mha_grads* g_att, const xnrs_additive_grads* g_pool, const xnrs_head_grads* g_head,
                              void* ws, size_t ws_bytes, void* stream_) {
+  return xnrs_seq_encoder_bwd_live(x, m, ids, n_seq, L, D, att, pool_kind, pool, head, saved, saved_bytes, dy, dx, g_att,
+                                   g_pool, g_head, nullptr, nullptr, 0, ws, ws_bytes, stream_);
+}
+
+int32_t xnrs_seq_encoder_bwd_live(const float* x, const float* m, const int32_t* ids, int64_t n_seq, int32_t L, int32_t D,
+                                  const xnrs_mha_params* att, int32_t pool_kind, const xnrs_additive_params* pool,
+                                  const xnrs_head_params* head, const void* saved, size_t saved_bytes, const float* dy,
+                                  float* dx, const xnrs_mha_grads* g_att, const xnrs_additive_grads* g_pool,
+                                  const xnrs_head_grads* g_head, const int32_t* live_rows, const int32_t* live_src_rows,
+                                  int64_t n_live, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n_seq == 0) return XNRS_OK;
   if (n_seq < 0 || L <= 0 || D <= 0 || !x || !dy) return XNRS_EINVAL;
@@ -740,6 +768,13 @@ int32_t xnrs_seq_encoder_bwd(const float* x, const float* m, const int32_t* ids,
   float* csum = reinterpret_cast<float*>(w + bp.off_colsum);
   float* wt = reinterpret_cast<float*>(w + bp.off_wt);
   const int64_t rows = n_seq * L;
+  // Live rows (optional): the unmasked token rows.  A masked row has pooling weight 0, so every gradient that passes
+  // through it is exactly zero (dy_i = a_i dp = 0, dpre_i = 0, dO_i = 0, dS_i = 0): the row-parallel GEMMs of the
+  // attention tower run over the live rows only, in place.  K and V gradients stay dense (padded rows are keys).
+  const bool live = live_rows && att && pooled && additive && m && n_live >= 0 && n_live < rows;
+  const int32_t* lv = live ? live_rows : nullptr;
+  const int32_t* lvx = live ? (live_src_rows ? live_src_rows : live_rows) : nullptr;
+  if (live_rows && ids && !live_src_rows) return XNRS_EINVAL;  // a gathered table needs the table rows of the live tokens
 
   // gradient w.r.t. the sequence rows that fed the pooler (att output, or x itself)
   const float* dseq_src = nullptr;  // [rows, D]
@@ -780,9 +815,11 @@ int32_t xnrs_seq_encoder_bwd(const float* x, const float* m, const int32_t* ids,
       XNRS_TRY(launch_additive_pool_bwd(pa, stream));
       if (g_pool && g_pool->w2) XNRS_TRY(launch_colsum(t, A, de, rows, A, g_pool->w2, csum, stream));
       if (g_pool && g_pool->b2) XNRS_TRY(launch_colsum(de, 1, nullptr, rows, 1, g_pool->b2, csum, stream));
-      if (g_pool && g_pool->w1) XNRS_TRY(gemm_dw(dpre, A, seq, seq_ids, L, D, g_pool->w1, rows, A, D, slabs, stream));
+      if (g_pool && g_pool->w1)
+        XNRS_TRY(gemm_dw(dpre, A, seq, seq_ids, L, D, g_pool->w1, rows, A, D, slabs, stream, lv, lv, n_live));  // live => att: seq = yatt
       if (g_pool && g_pool->b1) XNRS_TRY(launch_colsum(dpre, A, nullptr, rows, A, g_pool->b1, csum, stream));
-      if (need_dseq) XNRS_TRY(gemm_dx(dpre, A, pool->w1, dseq_dst, D, rows, A, D, nullptr, 0, 0, /*accumulate*/ 1, stream, wt));
+      if (need_dseq)
+        XNRS_TRY(gemm_dx(dpre, A, pool->w1, dseq_dst, D, rows, A, D, nullptr, 0, 0, /*accumulate*/ 1, stream, wt, lv, n_live));
     } else if (need_dseq) {
       XNRS_TRY(launch_mean_pool_bwd(dpool, m, ids, dseq_dst, D, n_seq, L, D, stream));
     }
@@ -793,9 +830,10 @@ int32_t xnrs_seq_encoder_bwd(const float* x, const float* m, const int32_t* ids,
   if (!att) return XNRS_OK;
 
   // ---- out projection: yatt = O Wo^T + bo
-  if (g_att && g_att->wo) XNRS_TRY(gemm_dw(dseq_src, D, o, nullptr, 0, D, g_att->wo, rows, D, D, slabs, stream));
+  if (g_att && g_att->wo) XNRS_TRY(gemm_dw(dseq_src, D, o, nullptr, 0, D, g_att->wo, rows, D, D, slabs, stream, lv, lv, n_live));
   if (g_att && g_att->bo) XNRS_TRY(launch_colsum(dseq_src, D, nullptr, rows, D, g_att->bo, csum, stream));
-  XNRS_TRY(gemm_dx(dseq_src, D, att->wo, docat, D, rows, D, D, nullptr, 0, 0, 0, stream, wt));
+  if (live) XNRS_TRY(hipMemsetAsync(docat, 0, (size_t)rows * D * sizeof(float), stream));  // dO of a masked row is zero
+  XNRS_TRY(gemm_dx(dseq_src, D, att->wo, docat, D, rows, D, D, nullptr, 0, 0, 0, stream, wt, lv, n_live));
   // ---- attention core
   MhaBwdArgs mb{};
   mb.q = qkv;
@@ -821,6 +859,7 @@ int32_t xnrs_seq_encoder_bwd(const float* x, const float* m, const int32_t* ids,
   mb.scaled = att->scaled;
   mb.dropout_p = att->dropout_p;
   mb.seed = att->seed;
+  mb.masked_do_is_zero = (pooled && m) ? 1 : 0;  // both poolers give masked rows a zero gradient
   XNRS_TRY(launch_mha_bwd(mb, stream));
   // ---- Q/K/V projections
   float* gw[3] = {g_att ? g_att->wq : nullptr, g_att ? g_att->wk : nullptr, g_att ? g_att->wv : nullptr};
@@ -828,7 +867,12 @@ int32_t xnrs_seq_encoder_bwd(const float* x, const float* m, const int32_t* ids,
   const float* wqkv[3] = {att->wq, att->wk, att->wv};
   for (int s3 = 0; s3 < 3; ++s3) {
     const float* dpart = dqkv + (int64_t)s3 * D;
-    if (gw[s3]) XNRS_TRY(gemm_dw(dpart, 3 * (int64_t)D, x, ids, L, D, gw[s3], rows, D, D, slabs, stream));
+    if (gw[s3]) {
+      if (s3 == 0 && live)  // dQ is zero on masked rows; dK / dV are not (padded tokens are keys)
+        XNRS_TRY(gemm_dw(dpart, 3 * (int64_t)D, x, nullptr, 0, D, gw[s3], rows, D, D, slabs, stream, lv, lvx, n_live));
+      else
+        XNRS_TRY(gemm_dw(dpart, 3 * (int64_t)D, x, ids, L, D, gw[s3], rows, D, D, slabs, stream));
+    }
     if (gb[s3]) XNRS_TRY(launch_colsum(dpart, 3 * (int64_t)D, nullptr, rows, D, gb[s3], csum, stream));
     if (dx) XNRS_TRY(gemm_dx(dpart, 3 * (int64_t)D, wqkv[s3], dx, D, rows, D, D, nullptr, 0, 0, s3 > 0 ? 1 : 0, stream, wt));
   }

@@ -214,7 +214,12 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
         if (only >= 0 && only != i) continue;
         const int64_t k = k0 + kA + KRA * i;
         const bool kok = k < kend;
-        const float* ptr = a.A + (kok ? k : kbeg) * a.lda;
+        int64_t srck = kok ? k : kbeg;
+        if (a.gather_ids) {
+          const int64_t n = srck / a.gather_S;
+          srck = (int64_t)a.gather_ids[n] * a.gather_S + (srck - n * a.gather_S);
+        }
+        const float* ptr = a.A + srck * a.lda;
         if (VEC) {
           ra[p][i] = *reinterpret_cast<const f32x4*>((kok && a_ok) ? ptr + mi : g_zero_line);
         } else {
@@ -438,8 +443,12 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int64_t row = m0 + wm * 32 * TM + 32 * i + (e & 3) + 8 * (e >> 2) + crow;
+        int64_t row = m0 + wm * 32 * TM + 32 * i + (e & 3) + 8 * (e >> 2) + crow;
         if (row < a.M) {
+          if (!A_COL && a.c_scatter) {  // row subset in place: C (and aux) rows follow A's gather
+            const int64_t n = row / a.gather_S;
+            row = (int64_t)a.gather_ids[n] * a.gather_S + (row - n * a.gather_S);
+          }
           float v = acc[i][j][e];
           if (!split) {
             v += bv;

@@ -258,8 +258,12 @@ __global__ __launch_bounds__(256, MINW) void gemm_split_kernel(GemmArgs a, int m
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int64_t row = m0 + wm * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + crow;
+        int64_t row = m0 + wm * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + crow;
         if (row < a.M) {
+          if (a.c_scatter) {  // row subset in place (see gemm_f32_kernel)
+            const int64_t n = row / a.gather_S;
+            row = (int64_t)a.gather_ids[n] * a.gather_S + (row - n * a.gather_S);
+          }
           float v = acc[i][j][e] + bv;
           if (a.act == 1) v = fmaxf(v, 0.f);
           else if (a.act == 2) v = tanhf(v);

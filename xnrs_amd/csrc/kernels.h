@@ -16,8 +16,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct GemmArgs {
   const float* A;
   int32_t a_col;              // 0: A[m][k] row-major (lda = row stride); 1: A given k-major, A^T[k][m] (lda = k stride)
-  const int32_t* gather_ids;  // nullable (ROW A only): logical row m -> table row ids[m/gather_S]*gather_S + m%gather_S
+  const int32_t* gather_ids;  // nullable: logical row m of A (ROW layout), or logical k row of a k-major A (a_col),
+                              // is physical row ids[m/gather_S]*gather_S + m%gather_S
   int32_t gather_S;
+  int32_t c_scatter;          // 1 (ROW A with gather_ids): logical row m of C is that same physical row -- the GEMM
+                              // works on a row subset of A and C in place (backward over the unmasked token rows)
   int64_t lda;
   const float* W[3];
   const float* bias[3];  // nullable each
@@ -104,6 +107,8 @@ struct MhaBwdArgs {
   int32_t scaled;
   float dropout_p;
   uint64_t seed;
+  int32_t masked_do_is_zero;  // 1: the caller guarantees d_o == 0 on rows with mask == 0 (a masked pooler sits on top):
+                              // query tiles whose 16 rows are all masked are skipped (their dQ rows are written as 0)
 };
 hipError_t launch_mha_bwd(const MhaBwdArgs& a, hipStream_t stream);
 

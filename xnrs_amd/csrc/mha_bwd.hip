@@ -366,6 +366,22 @@ __global__ __launch_bounds__(256) void mha_bwd_fused_kernel(MhaBwdArgs a) {
   __syncthreads();
 
   for (int qt = 0; qt < QT; ++qt) {
+    if (a.masked_do_is_zero && a.mask) {
+      // all 16 queries of this tile masked (or beyond S): S / dPd / dS are dead and dO is zero, so nothing reaches
+      // dK, dV or dQ -- uniform over the workgroup (depends on qt only), so the barriers below are skipped together
+      const int qq = qt * 16 + c;
+      const bool lv = qq < S && a.mask[mrow + qq] != 0.f;
+      if (!__any(lv)) {
+        if (wave == (qt & 3)) {
+          for (int idx = lane; idx < 16 * NCH; idx += 64) {
+            const int qr = idx / NCH, f0 = (idx - qr * NCH) * 4;
+            if (qt * 16 + qr < S && f0 < dk)
+              *reinterpret_cast<f32x4*>(a.dq + (row0 + qt * 16 + qr) * a.ldd + hoff + f0) = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+        continue;
+      }
+    }
     if (active) {
       f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

@@ -27,7 +27,7 @@ SYMBOLS = (
     "xnrs_set_gemm_mode", "xnrs_get_gemm_mode",
     "xnrs_text_encoder_unpadded_workspace_bytes", "xnrs_text_encoder_fwd_unpadded",
     "xnrs_seq_encoder_saved_bytes", "xnrs_seq_encoder_fwd_train", "xnrs_seq_encoder_bwd_workspace_bytes",
-    "xnrs_seq_encoder_bwd", "xnrs_linear_bwd_workspace_bytes", "xnrs_linear_bwd",
+    "xnrs_seq_encoder_bwd", "xnrs_seq_encoder_bwd_live", "xnrs_linear_bwd_workspace_bytes", "xnrs_linear_bwd",
     "xnrs_embedding_linear_bwd_workspace_bytes", "xnrs_embedding_linear_bwd", "xnrs_dot_scoring_bwd",
     "xnrs_assemble_train_batch", "xnrs_assemble_eval_batch", "xnrs_score_csr", "xnrs_rank_metrics",
     "xnrs_infonce_saved_bytes", "xnrs_infonce_fwd", "xnrs_infonce_bwd",
@@ -125,6 +125,10 @@ def lib():
     l.xnrs_seq_encoder_bwd.argtypes = [p, p, p, i64, i32, i32, C.POINTER(MhaParams), i32, C.POINTER(AdditiveParams),
                                        C.POINTER(HeadParams), p, sz, p, p, C.POINTER(MhaGrads), C.POINTER(AdditiveGrads),
                                        C.POINTER(HeadGrads), p, sz, p]
+    l.xnrs_seq_encoder_bwd_live.restype = i32
+    l.xnrs_seq_encoder_bwd_live.argtypes = [p, p, p, i64, i32, i32, C.POINTER(MhaParams), i32, C.POINTER(AdditiveParams),
+                                            C.POINTER(HeadParams), p, sz, p, p, C.POINTER(MhaGrads), C.POINTER(AdditiveGrads),
+                                            C.POINTER(HeadGrads), p, p, i64, p, sz, p]
     l.xnrs_linear_bwd_workspace_bytes.restype = sz
     l.xnrs_linear_bwd_workspace_bytes.argtypes = [i64, i32, i32]
     l.xnrs_linear_bwd.restype = i32
