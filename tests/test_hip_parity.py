@@ -376,3 +376,20 @@ def test_unpadded_encoder_matches_padded(tower):
         from xnrs_amd.hip import XnrsHipError
         with pytest.raises(XnrsHipError):
             ops.text_encoder_unpadded(x, m * 0.5, enc)
+
+
+def test_naml_with_padding_free_encoders_matches_golden():
+    """NAML (naml.py:61-147): title and abstract towers with skip_empty + unpadded switched on still reproduce the
+    golden vectors of the real reference."""
+    g = H.golden("models")
+    name = next(k for k in sorted(cases.MODELS) if cases.MODELS[k]["model"] == "NAML")
+    c = cases.MODELS[name]
+    model, sd = load(make_model(Cfg(cases.model_cfg(c))), c["seed"] + 1)
+    batch = cases.model_batch(c)
+    for enc in (model.title_encoder, model.body_encoder):
+        enc.skip_empty = enc.unpadded = True
+    with torch.no_grad():
+        r = model(batch)
+        ue = model.get_user_embeddings(batch)
+    H.assert_close(r, g[f"{name}/r"], what=name + " scores")
+    H.assert_close(ue, g[f"{name}/ue"], what=name + " ue")
