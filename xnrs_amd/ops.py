@@ -331,7 +331,12 @@ def text_encoder_unpadded(x, m, enc, ids=None):
     att, pooler, head = enc.att, enc.pooler, getattr(enc, "head", None)
     _check_att(att)
     p, _ = _att_dropout(att)
-    if _needs_grad(x, enc) or p > 0.0:
+    S, D = x.shape[-2], x.shape[-1]
+    dk = D // att.h if att is not None else 4
+    # outside the unpadded kernels' range (S, d_k <= 64, 16-byte aligned head rows) the padded kernels give the same
+    # result -- an optional speed-up never turns into an error
+    supported = S <= 64 and D % 4 == 0 and (att is None or (dk <= 64 and dk % 4 == 0))
+    if _needs_grad(x, enc) or p > 0.0 or not supported:
         return text_encoder(x, m, enc, ids=ids)
     return text_encoder_forward_unpadded(x, m, att, pooler, head, ids=ids)
 
