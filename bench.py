@@ -423,6 +423,56 @@ def latency_extra(device, reps=50):
     return dict(eager_ms=eager * 1e3, hipgraph_ms=graph * 1e3)
 
 
+def train_scaling(args, device, rank, world, dist_on):
+    """--train: the grad step of the reference (training.py:402-431) as a data-parallel job.  Weak scaling: every
+    rank owns 64 impressions (mind_small_NRMS.yml batch size; mind_small_CL.yml uses 16 -- too little work per GPU,
+    SURVEY.md section 8e), weights replicated.  Per step: local forward (one history encode feeding scores and user
+    embeddings), relu/MSE on the local impressions, InfoNCE over the GLOBAL batch (differentiable all-gather of the
+    user embeddings + labels), backward, one flat SUM all-reduce of the gradients, Adam."""
+    from xnrs_amd import distributed as D
+    from xnrs_amd.losses import contrastive_loss as infonce
+    w = dict(B=64, H=25, C=5, S=50, D=768, h=16, E=256, A=256)
+    model, _ = build_model(w, device, model_name="NRMS" if args.train == "nrms" else "standard")
+    model.train()
+    if dist_on:
+        D.broadcast_parameters(model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    hist, cand = make_inputs(w, device, seed=2000 + rank)
+    targets = torch.zeros(w["B"], w["C"], 1, device=device)
+    targets[:, 0] = 1.0
+    gen = torch.Generator(device=device)
+    gen.manual_seed(3000 + rank)
+    labels = torch.randint(0, 6, (w["B"],), device=device, generator=gen)
+    batch = {"user_features": {"history": {"title_emb": hist}, "other": {}}, "candidate_features": {"title_emb": cand}}
+    n_global = w["B"] * (world if dist_on else 1)
+
+    def fn():
+        opt.zero_grad()
+        r, u, _ = model(batch, return_embeddings=True)
+        rec = torch.nn.functional.mse_loss(torch.relu(r), targets)
+        if dist_on:
+            cl = infonce(D.all_gather_rows(u.squeeze(1)), D.all_gather_labels(labels), 0.08)
+            loss = D.global_train_loss(rec, w["B"], n_global, cl, 0.1)
+        else:
+            loss = rec + 0.1 * infonce(u.squeeze(1), labels, 0.08)
+        loss.backward()
+        if dist_on:
+            D.allreduce_gradients(model.parameters())
+        opt.step()
+        return loss
+    dt = timed(fn, args.steps, args.warmup, dist_on)
+    n_gpus = world if dist_on else 1
+    return {"metric": "train impressions/sec (forward + loss + backward + gradient all-reduce + Adam)",
+            "value": n_global * args.steps / dt, "unit": "impressions/s", "n_gpus": n_gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": GEMM_MODES[args.gemm_mode][0], "data": "synthetic",
+            "config": {"workload": f"{args.train} grad step, 64 impressions per GPU (H=25, C=5, S=50, D=768), global in-batch "
+                                   "InfoNCE (lambda 0.1, tau 0.08), attention dropout 0.1",
+                       "parallelism": f"impressions sharded over {n_gpus} GPU(s); all-gather of (64, 256) user embeddings + "
+                                      "one flat fp32 gradient all-reduce per step"},
+            "loss_finite": bool(torch.isfinite(fn()).item())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -433,6 +483,10 @@ def main():
     ap.add_argument("--gemm-mode", type=int, default=0, choices=(0, 1, 2),
                     help="arithmetic of the forward GEMMs for the HEADLINE line: 0 exact fp32 MFMA (default), "
                          "1 bf16x3 split, 2 bf16x2 split; the default run reports modes 1 and 2 under extra")
+    ap.add_argument("--train", choices=("nrms", "standard"), default=None,
+                    help="time the data-parallel GRAD step instead (BASELINE configs[3]: impressions sharded over the "
+                         "ranks, global in-batch InfoNCE through a differentiable all-gather, one flat RCCL gradient "
+                         "all-reduce); prints its own JSON line")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -451,6 +505,14 @@ def main():
 
     hip.set_gemm_mode(args.gemm_mode)  # explicit: the environment (XNRS_GEMM_MODE) never changes the headline
     mode_name, mode_products = GEMM_MODES[args.gemm_mode]
+    if args.train:
+        out = train_scaling(args, device, rank, world, dist_on)
+        if rank == 0:
+            print(json.dumps(out))
+        if dist_on:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return
     w = WORKLOAD
     model, sd = build_model(w, device)
     hist, cand = make_inputs(w, device, seed=1000 + rank)  # each rank = its own shard of users
