@@ -26,6 +26,7 @@ struct Plan {
   int64_t chunk;  // sequences per pass
   size_t off_qkv, off_o, off_y, off_t, off_p, off_h;
   size_t off_stats, off_a;  // training only: softmax row statistics, pooling weights
+  size_t off_planes;        // bf16-split GEMM modes: pre-split weight planes (wq, wk, wv, wo, w1)
   size_t total;
 };
 
@@ -55,6 +56,11 @@ Plan make_plan(int64_t n_seq, int L, int D, int A, int E, bool att, bool additiv
   p.off_h = (pooled && head) ? take((size_t)n_seq * E) : 0;
   p.off_stats = (train && att) ? take((size_t)chunk * n_heads * L * 2) : 0;
   p.off_a = (train && additive) ? take(rows) : 0;
+  // always reserved (15 MB at D = 768), so the plan does not depend on the GEMM mode of the moment
+  size_t pl = 0;
+  if (att) pl += 4 * align_up(split_planes_bytes(D, D));
+  if (pooled && additive) pl += align_up(split_planes_bytes(A, D));
+  p.off_planes = take((pl + 3) / 4);
   p.total = off;
   return p;
 }
@@ -100,8 +106,10 @@ struct ProfScope {
   } while (0)
 
 GemmArgs gemm1(const float* A, const int32_t* ids, int gS, int64_t lda, const float* W, const float* b, float* C,
-               int64_t ldc, int64_t M, int N, int K, int act) {
+               int64_t ldc, int64_t M, int N, int K, int act, const unsigned short* planes = nullptr) {
   GemmArgs g{};
+  g.Wp[0] = planes;
+  g.ldp = split_plane_ld(K);
   g.A = A;
   g.gather_ids = ids;
   g.gather_S = gS;
@@ -157,6 +165,24 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
   float* pb = reinterpret_cast<float*>(w + p.off_p);
   float* hb = reinterpret_cast<float*>(w + p.off_h);
 
+  // bf16-split GEMM modes: split the weights ONCE per call (the chunk loop below reuses them ~20 times per step)
+  const unsigned short *pq = nullptr, *pk = nullptr, *pv = nullptr, *po = nullptr, *p1 = nullptr;
+  if (gemm_mode() != 0) {
+    char* pw = w + p.off_planes;
+    auto prep = [&](const float* W, int N, int K) -> const unsigned short* {
+      unsigned short* dst = reinterpret_cast<unsigned short*>(pw);
+      pw += align_up(split_planes_bytes(N, K));
+      return launch_split_weights(W, N, K, dst, stream) == hipSuccess ? dst : nullptr;
+    };
+    if (att) {
+      pq = prep(att->wq, D, D);
+      pk = prep(att->wk, D, D);
+      pv = prep(att->wv, D, D);
+      po = prep(att->wo, D, D);
+    }
+    if (pooled && additive) p1 = prep(pool->w1, A, D);
+  }
+
   for (int64_t c0 = 0; c0 < n_seq; c0 += p.chunk) {
     const int64_t nc = (n_seq - c0 < p.chunk) ? (n_seq - c0) : p.chunk;
     const int64_t rows = nc * L;
@@ -174,6 +200,8 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
       g.gather_S = L;
       g.lda = D;
       g.W[0] = att->wq; g.W[1] = att->wk; g.W[2] = att->wv;
+      g.Wp[0] = pq; g.Wp[1] = pk; g.Wp[2] = pv;
+      g.ldp = split_plane_ld(D);
       g.bias[0] = att->bq; g.bias[1] = att->bk; g.bias[2] = att->bv;
       g.nseg = 3;
       g.Nseg = D;
@@ -219,7 +247,7 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
       float* dst = pooled ? yb : y + c0 * (int64_t)L * D;
       {
         ProfScope ps(2, 2.0 * rows * (double)D * D, stream);
-        XNRS_TRY(launch_gemm_f32(gemm1(o, nullptr, 0, D, att->wo, att->bo, dst, D, rows, D, D, XNRS_ACT_NONE), stream));
+        XNRS_TRY(launch_gemm_f32(gemm1(o, nullptr, 0, D, att->wo, att->bo, dst, D, rows, D, D, XNRS_ACT_NONE, po), stream));
       }
       seq = dst;
       seq_ids = nullptr;
@@ -231,7 +259,7 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
     if (additive) {
       {
         ProfScope ps(3, 2.0 * rows * (double)D * A, stream);
-        XNRS_TRY(launch_gemm_f32(gemm1(seq, seq_ids, L, D, pool->w1, pool->b1, t, A, rows, A, D, XNRS_ACT_TANH), stream));
+        XNRS_TRY(launch_gemm_f32(gemm1(seq, seq_ids, L, D, pool->w1, pool->b1, t, A, rows, A, D, XNRS_ACT_TANH, p1), stream));
       }
       AdditivePoolArgs pa{};
       pa.t = t;

@@ -47,7 +47,7 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
 __device__ __forceinline__ float lo_f32(unsigned p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float hi_f32(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
 
-template <int NPL, bool BUF, int MINW>
+template <int NPL, bool BUF, int MINW, bool BPRE = false>
 __global__ __launch_bounds__(256, MINW) void gemm_split_kernel(GemmArgs a, int m_tiles, int n_tiles_seg, int gn) {
   constexpr int BM = 128, BN = 128, BK = 16;
   constexpr int NPROD = NPL == 3 ? 6 : 3;
@@ -114,6 +114,22 @@ __global__ __launch_bounds__(256, MINW) void gemm_split_kernel(GemmArgs a, int m
     pb = W + (int64_t)col * a.ldw + 8 * shalf;
   }
 
+  // BPRE: the weights arrive pre-split (GemmArgs::Wp): plane p of this thread's (column, k half)
+  // layout (launch_split_weights): planes[p][k/16][n][16] -- the 128 x 16 tile of a k step is 4 KB contiguous, so the
+  // plane loads are fully coalesced raw buffer loads: per-plane byte offset in a VGPR, the k step in the scalar offset
+  __amdgpu_buffer_rsrc_t rsP;
+  unsigned offP[NPL];
+  int kstepP = 0;  // bytes per k step = Nseg * 32
+  if constexpr (BPRE) {
+    int colc = n0 + srow;
+    if (colc >= a.Nseg) colc = a.Nseg - 1;  // clamped: the columns beyond Nseg are discarded by the epilogue
+    const int64_t kb = a.ldp / 16;
+    rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.Wp[seg]), 0, (int)(3 * kb * a.Nseg * 32), 0x00020000);
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) offP[p] = (unsigned)(((p * kb * a.Nseg + colc) * 16 + 8 * shalf) * 2);
+    kstepP = a.Nseg * 32;
+  }
+  u32x4s rbp[NPL];     // BPRE: the bf16 planes of the NEXT stage as loaded
   f32x4 ra[2], rb[2];  // raw fp32 of the NEXT stage: k (8*shalf + 0..3) and (+4..7)
   auto gloadA = [&](int64_t k0) {
     const int64_t k = k0 + 8 * shalf;
@@ -128,7 +144,12 @@ __global__ __launch_bounds__(256, MINW) void gemm_split_kernel(GemmArgs a, int m
   };
   auto gloadB = [&](int64_t k0) {
     const int64_t k = k0 + 8 * shalf;
-    if constexpr (BUF) {
+    if constexpr (BPRE) {
+      (void)k;
+#pragma unroll
+      for (int p = 0; p < NPL; ++p)
+        rbp[p] = __builtin_bit_cast(u32x4s, __builtin_amdgcn_raw_buffer_load_b128(rsP, (int)offP[p], (int)(k0 >> 4) * kstepP, 0));
+    } else if constexpr (BUF) {
       const int soff = (int)(k0 * 4);
       rb[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(offB | (k < kend ? 0u : SPLIT_OOB)), soff, 0));
       rb[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)((offB + 16u) | (k + 4 < kend ? 0u : SPLIT_OOB)), soff, 0));
@@ -161,7 +182,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_split_kernel(GemmArgs a, int m
   };
   auto storeB = [&](int buf) {
 #pragma unroll
-    for (int p = 0; p < NPL; ++p) Bs[buf][p][st_chunk] = plB[p];
+    for (int p = 0; p < NPL; ++p) Bs[buf][p][st_chunk] = BPRE ? rbp[p] : plB[p];
   };
 
   f32x16 acc[2][2];
@@ -192,10 +213,12 @@ __global__ __launch_bounds__(256, MINW) void gemm_split_kernel(GemmArgs a, int m
       split_phase(ra, plA, j, 0);
       split_phase(ra, plA, j, 1);
     }
+    if constexpr (!BPRE) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      split_phase(rb, plB, j, 0);
-      split_phase(rb, plB, j, 1);
+      for (int j = 0; j < 4; ++j) {
+        split_phase(rb, plB, j, 0);
+        split_phase(rb, plB, j, 1);
+      }
     }
     storeA(0);
     storeB(0);
@@ -236,7 +259,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_split_kernel(GemmArgs a, int m
         if (n < 8) split_phase(ra, plA, n >> 1, n & 1);
         else if (n == 8) storeA(buf ^ 1);
         else if (n == 9) gloadA(kn);
-        else if (n < 18) split_phase(rb, plB, (n - 10) >> 1, (n - 10) & 1);
+        else if (n < 18) { if constexpr (!BPRE) split_phase(rb, plB, (n - 10) >> 1, (n - 10) & 1); }
         else if (n == 18) storeB(buf ^ 1);
         else gloadB(kn);
       }
@@ -279,6 +302,33 @@ __global__ __launch_bounds__(256, MINW) void gemm_split_kernel(GemmArgs a, int m
   }
 }
 
+// planes[p][k/16][n][16] of W[n][k]: the exact 3-way bf16 split (same arithmetic as split_phase), zero padded to ldp columns
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* W, int64_t N, int64_t K, int64_t ldp, unsigned short* planes) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one thread per PAIR of k
+  const int64_t pairs = ldp / 2;
+  if (i >= N * pairs) return;
+  const int64_t n = i / pairs, k = (i - n * pairs) * 2;
+  const float x0 = k < K ? W[n * K + k] : 0.f, x1 = k + 1 < K ? W[n * K + k + 1] : 0.f;
+  const unsigned h = pk_bf16(x0, x1);
+  const float r0 = x0 - lo_f32(h), r1 = x1 - hi_f32(h);
+  const unsigned m = pk_bf16(r0, r1);
+  const unsigned l = pk_bf16(r0 - lo_f32(m), r1 - hi_f32(m));
+  unsigned* out = reinterpret_cast<unsigned*>(planes);
+  const int64_t plane = N * pairs;
+  const int64_t o = ((k >> 4) * N + n) * 8 + ((k & 15) >> 1);  // [k/16][n][16] in pairs
+  out[o] = h;
+  out[plane + o] = m;
+  out[2 * plane + o] = l;
+}
+
+hipError_t launch_split_weights(const float* W, int64_t N, int64_t K, unsigned short* planes, hipStream_t stream) {
+  const int64_t ldp = split_plane_ld(K);
+  const int64_t n = N * (ldp / 2);
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, W, N, K, ldp, planes);
+  return hipGetLastError();
+}
+
 // forward-layout launcher; the caller (launch_gemm_f32) has checked: !a_col, !b_kn, no split-K, K % 4 == 0,
 // 16-byte aligned operands.  npl = 3 (six products, fp32-grade) or 2 (three products).
 hipError_t launch_gemm_split(const GemmArgs& a, int npl, hipStream_t stream) {
@@ -293,7 +343,15 @@ hipError_t launch_gemm_split(const GemmArgs& a, int npl, hipStream_t stream) {
                    (int64_t)a.Nseg * a.ldw * 4 <= (int64_t)SPLIT_OOB;
 #define XNRS_LAUNCH_SPLIT(NPLV, BUFV, MINWV) \
   hipLaunchKernelGGL((gemm_split_kernel<NPLV, BUFV, MINWV>), g, dim3(256), 0, stream, a, (int)m_tiles, n_tiles_seg, gn)
-  if (npl == 3) {
+  bool pre = a.Wp[0] != nullptr;
+  for (int s2 = 1; s2 < a.nseg; ++s2) pre = pre && a.Wp[s2] != nullptr;
+  if (pre && buf) {
+    if (npl == 3) hipLaunchKernelGGL((gemm_split_kernel<3, true, 3, true>), g, dim3(256), 0, stream, a, (int)m_tiles, n_tiles_seg, gn);
+    else hipLaunchKernelGGL((gemm_split_kernel<2, true, 3, true>), g, dim3(256), 0, stream, a, (int)m_tiles, n_tiles_seg, gn);
+  } else if (pre) {
+    if (npl == 3) hipLaunchKernelGGL((gemm_split_kernel<3, false, 3, true>), g, dim3(256), 0, stream, a, (int)m_tiles, n_tiles_seg, gn);
+    else hipLaunchKernelGGL((gemm_split_kernel<2, false, 3, true>), g, dim3(256), 0, stream, a, (int)m_tiles, n_tiles_seg, gn);
+  } else if (npl == 3) {
     if (buf) XNRS_LAUNCH_SPLIT(3, true, 3);
     else XNRS_LAUNCH_SPLIT(3, false, 3);
   } else {

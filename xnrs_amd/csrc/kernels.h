@@ -39,6 +39,11 @@ struct GemmArgs {
   int64_t ldaux;
   int32_t aux_mode;    // 0 none; 1: C *= (1 - aux^2) (tanh'); 2: C *= (aux > 0) (relu')
   int32_t accumulate;  // 1: C += result
+  // bf16-split modes only (nullable): the weights of segment s pre-split into bf16 planes [3][ldp/16][Nseg][16]
+  // (launch_split_weights; ldp = K rounded up to 16, zero padded) -- the kernel then loads B planes as they are
+  // instead of splitting the fp32 weights again in every row tile
+  const unsigned short* Wp[3];
+  int64_t ldp;
   // split-K (deterministic slabs + ordered reduce); set by the caller via slabs/nsplit
   float* slabs;        // nullable workspace of nsplit * M * ldc floats
   int32_t nsplit;
@@ -53,6 +58,11 @@ size_t gemm_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
 hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t stream);
 // forward-layout GEMM on the bf16 matrix cores by operand splitting (gemm_split.hip); npl = 3 or 2 planes
 hipError_t launch_gemm_split(const GemmArgs& a, int npl, hipStream_t stream);
+// planes[p][k/16][n][16] (p = 0..2: hi, mid, lo; k zero padded to ldp = split_plane_ld(K)) of W[N][K]: the
+// 128 x 16 tile of one k step is contiguous
+inline int64_t split_plane_ld(int64_t K) { return (K + 15) / 16 * 16; }
+inline size_t split_planes_bytes(int64_t N, int64_t K) { return (size_t)3 * (size_t)N * (size_t)split_plane_ld(K) * 2; }
+hipError_t launch_split_weights(const float* W, int64_t N, int64_t K, unsigned short* planes, hipStream_t stream);
 // 0: exact fp32 MFMA (default); 1: bf16x3 split, six products (fp32-grade); 2: bf16x2 split, three products.
 // Initialised from XNRS_GEMM_MODE; applies to the forward (ROW x WT) layout only.
 int gemm_mode();
