@@ -20,29 +20,7 @@ class Cfg(dict):
     __getattr__ = dict.__getitem__
 
 
-def synthetic_world(n_news=300, n_sess=400, S=6, D=32, n_topics=4, seed=0):
-    """News carry a topic direction in their tokens; a user clicks news of its own topic."""
-    rng = np.random.default_rng(seed)
-    topics = rng.standard_normal((n_topics, D)).astype(np.float32) * 2.0
-    news_topic = rng.integers(0, n_topics, size=n_news)
-    x = np.zeros((n_news + 1, S, D), dtype=np.float32)
-    m = np.zeros((n_news + 1, S), dtype=np.float32)
-    for i in range(n_news):
-        L = rng.integers(2, S + 1)
-        x[i + 1] = rng.standard_normal((S, D)) * 0.5 + topics[news_topic[i]]
-        m[i + 1, :L] = 1
-    store = NewsStore(torch.from_numpy(x), torch.from_numpy(m), list(range(n_news)))
-    by_topic = [np.where(news_topic == t)[0] + 1 for t in range(n_topics)]
-    others = [np.where(news_topic != t)[0] + 1 for t in range(n_topics)]
-    sessions = []
-    for s in range(n_sess):
-        t = int(rng.integers(0, n_topics))
-        sessions.append(dict(history=rng.choice(by_topic[t], size=int(rng.integers(2, 9))).tolist(),
-                             positives=rng.choice(by_topic[t], size=1).tolist(),
-                             negatives=rng.choice(others[t], size=int(rng.integers(4, 12))).tolist(),
-                             main_theme=f"topic{t}"))
-    store.index = {i + 1: i + 1 for i in range(n_news)}  # rows are used directly as ids here
-    return store, Behaviors.from_sessions(sessions, store)
+synthetic_world = synth.click_world
 
 
 @pytest.mark.parametrize("model_name", ["NRMS", "standard"])
