@@ -26,6 +26,8 @@ The JSON line also carries
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,7 +37,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from tests.golden import cases  # noqa: E402  (model_cfg: the flat YAML keys make_model reads)
 from xnrs_amd import hip, synth  # noqa: E402
 from xnrs_amd.models import make_model  # noqa: E402
 
@@ -76,7 +77,7 @@ def impression_bytes(w):
 
 def build_model(w, device, seed=1234, model_name="NRMS"):
     c = dict(model=model_name, E=w["E"], bias=False, h=w["h"], D=w["D"], H=w["H"], S=w["S"])
-    model = make_model(Cfg(cases.model_cfg(c)))
+    model = make_model(Cfg(synth.model_cfg(c)))
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     sd = synth.fill_state_dict(shapes, seed)
     model.load_state_dict(sd)
@@ -101,24 +102,92 @@ def step(model, hist, cand):
     return model._forward(hist, cand)
 
 
-def timed(fn, steps, warmup, dist_on):
+def timed(fn, steps, warmup, dist_on, device="cuda"):
+    """W untimed + EXACTLY `steps` timed calls bracketed by barrier + device sync on both sides; MAX over ranks."""
+    on_gpu = torch.device(device).type == "cuda"
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
     for _ in range(warmup):
         fn()
     if dist_on:
         torch.distributed.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
-    torch.cuda.synchronize()
+    sync()
     if dist_on:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
     if dist_on:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     return dt
+
+
+def count_ranks(device):
+    """SUM all-reduce of ones over the process group: the number of ranks the collective library (RCCL) really
+    joined.  Printed as `rccl_ranks` so a reader can tell an N-rank run from N copies of a 1-rank run."""
+    t = torch.ones(1, dtype=torch.float32, device=device)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
+    return int(round(float(t.item())))
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with no torch.distributed.run environment: start the N ranks here.
+
+    Runs BEFORE anything touches the GPU in this process (device_count() does not initialise it), starts one fresh
+    child interpreter per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (children, not an exec of this
+    process), lets rank 0 print the one JSON line on the inherited stdout, and exits with the worst child code.  A
+    rank that dies takes the others down (exact PIDs) instead of leaving them in a collective forever."""
+    n = args.gpus
+    if args.selftest_backend is None:
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} requested but only {have} GPU(s) are visible; refusing to print an "
+                  f"n_gpus={n} line from fewer devices", file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                for o in alive:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def selftest_line(args, rank, world):
+    """Launcher self-test (tests/test_bench_launcher.py): the rendezvous / barrier / MAX-over-ranks / rank-0-prints
+    contract of this file over gloo on CPU with a stub step.  No hot-path work is done or claimed."""
+    torch.distributed.init_process_group(args.selftest_backend, rank=rank, world_size=world)
+    x = torch.randn(64, 64)
+    dt = timed(lambda: x @ x, args.steps, args.warmup, True, device="cpu")
+    ranks = count_ranks("cpu")
+    if rank == 0:
+        print(json.dumps({"metric": "launcher self-test (stub step, no hot-path work)", "value": world * args.steps / dt,
+                          "unit": "stub steps/s", "n_gpus": world, "rccl_ranks": ranks, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "stub",
+                          "config": {"workload": "none (launcher self-test)", "backend": args.selftest_backend}}))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
 
 
 def usable_cores():
@@ -187,7 +256,7 @@ def other_models_extra(device, steps=5, warmup=2):
     gen.manual_seed(11)
     for name in ("standard", "NAML"):
         c = dict(model=name, E=256, bias=False, h=16, D=D, H=H, S=S)
-        model = make_model(Cfg(cases.model_cfg(c)))
+        model = make_model(Cfg(synth.model_cfg(c)))
         shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
         model.load_state_dict(synth.fill_state_dict(shapes, 99))
         model = model.eval().to(device)
@@ -487,26 +556,48 @@ def main():
                     help="time the data-parallel GRAD step instead (BASELINE configs[3]: impressions sharded over the "
                          "ranks, global in-batch InfoNCE through a differentiable all-gather, one flat RCCL gradient "
                          "all-reduce); prints its own JSON line")
+    ap.add_argument("--selftest-backend", choices=("gloo",), default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
 
+    # ---- rank environment.  torch.distributed.run (the driver's N>1 launch) sets WORLD_SIZE; a bare
+    # `python bench.py --gpus N` does not, and then THIS process is only the parent of the N ranks.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        # never print an n_gpus that differs from what was asked for
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with --nproc-per-node {args.gpus} "
+              f"(or without a launcher: bench.py starts the ranks itself)", file=sys.stderr)
+        sys.exit(2)
+    if args.selftest_backend:
+        selftest_line(args, rank, world)
+        return
     # XNRS_BENCH_FORCE_DIST=1 exercises the RCCL init / barrier / MAX-reduce path with a single rank
     dist_on = world > 1 or os.environ.get("XNRS_BENCH_FORCE_DIST") == "1"
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if local_rank >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank} needs GPU {local_rank} but {torch.cuda.device_count()} are visible", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    rccl_ranks = None
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        rccl_ranks = count_ranks(device)
+        if rccl_ranks != world:
+            print(f"bench.py: RCCL all-reduce saw {rccl_ranks} ranks, expected {world}", file=sys.stderr)
+            sys.exit(3)
 
     hip.set_gemm_mode(args.gemm_mode)  # explicit: the environment (XNRS_GEMM_MODE) never changes the headline
     mode_name, mode_products = GEMM_MODES[args.gemm_mode]
     if args.train:
         out = train_scaling(args, device, rank, world, dist_on)
+        out["rccl_ranks"] = rccl_ranks
         if rank == 0:
             print(json.dumps(out))
         if dist_on:
@@ -546,6 +637,7 @@ def main():
             "value": value,
             "unit": "impressions/s",
             "n_gpus": n_gpus,
+            "rccl_ranks": rccl_ranks,  # SUM all-reduce of ones over RCCL (null: single process, no process group)
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,

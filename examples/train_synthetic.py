@@ -17,7 +17,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tests.golden import cases  # noqa: E402  (model_cfg: the reference's YAML keys with their shipped defaults)
 from xnrs_amd import evaluation, hip, synth  # noqa: E402
 from xnrs_amd.data import DeviceBatcher  # noqa: E402
 from xnrs_amd.losses import contrastive_loss  # noqa: E402
@@ -42,7 +41,7 @@ def main():
     torch.manual_seed(0)
     store, beh = synth.click_world(n_news=2000, n_sess=4000, S=12, D=64, n_topics=6)
     store, beh = store.to(dev), beh.to(dev)
-    cfg = Cfg(cases.model_cfg(dict(model=args.model, E=64, bias=True, h=4, D=64, H=args.hist, S=12)))
+    cfg = Cfg(synth.model_cfg(dict(model=args.model, E=64, bias=True, h=4, D=64, H=args.hist, S=12)))
     model = make_model(cfg).to(dev)
     model.news_encoder.skip_empty = True          # empty history slots share one encoded representative (exact)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)

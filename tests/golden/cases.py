@@ -69,14 +69,9 @@ GRAD = dict(model="NRMS", B=4, H=3, C=3, S=8, D=32, h=4, E=16, bias=False, seed=
 
 
 def model_cfg(c: dict) -> dict:
-    """The flat YAML keys make_model reads (xnrs/models/make_model.py:17-18, nrms.py:12-41,
-    naml.py:12-59), at the case's shape."""
-    return dict(
-        model=c["model"], scoring="dot", total_emb_dim=c["E"], title_emb_dim=c["E"], bias=c["bias"],
-        n_heads=c["h"], d_backbone=c["D"], p_dropout=0.0, cat_emb_dim=16, sub_emb_dim=16,
-        n_categories=19, n_subcategories=300, catg_features=[], text_features=["title_emb"],
-        user_features=[], add_features=[], hist_len=c["H"], seq_len=c["S"],
-    )
+    """The flat YAML keys make_model reads, at the case's shape (one definition: xnrs_amd.synth.model_cfg)."""
+    from xnrs_amd import synth
+    return synth.model_cfg(c)
 
 
 def theme_labels(themes):

@@ -149,3 +149,14 @@ def click_world(n_news=300, n_sess=400, S=6, D=32, n_topics=4, seed=0):
                              main_theme=f"topic{t}"))
     store.index = {i + 1: i + 1 for i in range(n_news)}  # rows are used directly as ids here
     return store, Behaviors.from_sessions(sessions, store)
+
+
+def model_cfg(c: dict) -> dict:
+    """The flat YAML keys make_model reads (xnrs/models/make_model.py:17-18, nrms.py:12-41, naml.py:12-59) with the
+    shipped configs' defaults, at the shape given by c = {model, E, bias, h, D, H, S}."""
+    return dict(
+        model=c["model"], scoring="dot", total_emb_dim=c["E"], title_emb_dim=c["E"], bias=c["bias"],
+        n_heads=c["h"], d_backbone=c["D"], p_dropout=0.0, cat_emb_dim=16, sub_emb_dim=16,
+        n_categories=19, n_subcategories=300, catg_features=[], text_features=["title_emb"],
+        user_features=[], add_features=[], hist_len=c["H"], seq_len=c["S"],
+    )
