@@ -12,9 +12,13 @@
  *   - all tensors are contiguous row-major fp32 DEVICE pointers unless stated; masks are fp32 0/1
  *     exactly like the reference (news_encoding.py:34-50); ids are int32 device pointers.
  *   - nn.Linear weights keep the reference layout W[out][in] (K-contiguous), bias[out] or NULL.
- *   - no allocation, no global state, no host sync: the caller supplies the workspace (size from
- *     the *_workspace_bytes query) and a hipStream_t (as void*; NULL = default stream).  Safe to
- *     capture into a hipGraph.
+ *   - no allocation and no host sync: the caller supplies the workspace (size from the
+ *     *_workspace_bytes query) and a hipStream_t (as void*; NULL = default stream).  Safe to capture
+ *     into a hipGraph.
+ *   - process-global state (documented at its entry points, nothing else exists): the forward-GEMM
+ *     arithmetic mode (xnrs_set_gemm_mode), the development knobs (xnrs_reload_knobs) and the optional
+ *     launch timer (xnrs_profile_*).  Encode / score calls on different streams may run from different
+ *     threads; changing one of the three while another thread launches is the caller's race.
  *   - return value: 0 = ok; >0 = hipError_t of the failed launch; <0 = XNRS_E* argument error.
  *     xnrs_error_string() explains either.
  */
@@ -254,13 +258,14 @@ int32_t xnrs_infonce_bwd(const int64_t *labels, int64_t B, int32_t E, float temp
 
 /* ---- measurement aid (no reference counterpart) ----------------------------------------------
  * When enabled, the sequence-encoder pipeline brackets each kernel launch of the selected stages
- * with hipEvents on the caller's stream (the only process-global state in the library; off by
- * default; not hipGraph-capturable while on).  stage_mask bit i selects stage i:
+ * with hipEvents on the caller's stream (process-global, mutex-guarded; off by default; not
+ * hipGraph-capturable while on).  stage_mask bit i selects stage i:
  *   0 qkv GEMM | 1 attention core | 2 out-proj GEMM | 3 fc1+tanh GEMM | 4 pooling | 5 head GEMMs
+ *   6 fused short-sequence encoder (stages 0-4 in one launch: S <= 32, D <= 320, news_fused.hip)
  * xnrs_profile_read synchronises the recorded events and returns, per stage, the summed launch
  * duration (ms), the number of launches and the summed ALGORITHMIC flops of those launches
  * (arrays of XNRS_PROFILE_STAGES entries), then clears the record. */
-#define XNRS_PROFILE_STAGES 6
+#define XNRS_PROFILE_STAGES 7
 int32_t xnrs_profile_enable(uint32_t stage_mask);
 int32_t xnrs_profile_read(double *ms, int64_t *launches, double *flops);
 
@@ -268,8 +273,10 @@ int32_t xnrs_profile_read(double *ms, int64_t *launches, double *flops);
  *   XNRS_GEMM_F32     (0, default) v_mfma_f32_32x32x2_f32: an exact fp32 fmaf chain.
  *   XNRS_GEMM_BF16X3  (1) each fp32 operand is split exactly into three bf16 pieces and the product is
  *                     rebuilt from six v_mfma_f32_32x32x16_bf16 with fp32 accumulation: dropped terms are
- *                     <= 2^-26 |a||b| per product, i.e. below one fp32 rounding (measured on the full
- *                     workload: same distance to the CPU oracle as mode 0).
+ *                     <= 2^-26 |a||b| per product.  Measured against an fp64 product: as close as mode 0 on
+ *                     N(0,1) operands (7.6e-7 vs 9.5e-7 normwise), about 2x mode 0's error on operands
+ *                     with a wide dynamic range (5.5e-7 vs 2.4e-7; tests/test_hip_split_gemm.py bounds it
+ *                     at 1e-6); same distance to the CPU oracle as mode 0 on the full workload.
  *   XNRS_GEMM_BF16X2  (2) two pieces, three products: ~1e-5 relative per product; an opt-in speed knob.
  * Process-wide; the initial value comes from the environment variable XNRS_GEMM_MODE.  It covers every GEMM
  * that runs on the forward-layout kernel: the nn.Linear forwards and the input-gradient products dX = dY . W of
@@ -282,6 +289,13 @@ int32_t xnrs_profile_read(double *ms, int64_t *launches, double *flops);
 #define XNRS_GEMM_BF16X2 2
 int32_t xnrs_set_gemm_mode(int32_t mode);
 int32_t xnrs_get_gemm_mode(void);
+
+/* ---- development knobs (no reference counterpart) ---------------------------------------------
+ * Kernel-selection switches for A/B measurements and tests (XNRS_GEMM_PIPE, _BK, _BUF, _GROUP, _TILE,
+ * XNRS_GEMM_SPLIT_MIN_TILES, XNRS_MHA_LDS, XNRS_MHA_HEADWAVE, XNRS_MHA_BWD_FUSED, XNRS_NEWS_FUSED; DESIGN.md
+ * section 6).  The library reads them from the environment ONCE when it is loaded -- no launch calls getenv --
+ * and again only when this function is called.  None changes a result beyond summation order. */
+int32_t xnrs_reload_knobs(void);
 
 #ifdef __cplusplus
 }

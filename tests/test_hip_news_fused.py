@@ -1,0 +1,131 @@
+"""GPU: the fused short-title news encoder (xnrs_amd/csrc/news_fused.hip: attention + additive pooling of
+TextEncoder.forward, news_encoding.py:48-54 / layers.py:60-65,128-154, in ONE launch for S <= 32, D <= 320).
+
+* it is the path that runs (the launch timer records stage `news_fused`, none of stages 0-4);
+* it equals the CPU oracle and the six-launch pipeline (XNRS_NEWS_FUSED=0) on a sweep of shapes that walks every
+  head-width instantiation (d_k = 4 .. 32), ragged head groups (h = 15), S on both sides of the 16-row tile edge,
+  odd news counts (the last workgroup is half empty), all-masked news, and the id-gather variant;
+* the golden vectors of the real reference at the configs[1] shapes go through it (tests/test_hip_parity.py runs
+  `news_nrms_300`, `news_nrms_tiny`, `nrms_300` on the default dispatch, i.e. this kernel)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import xnrs_oracle as O
+from tests import helpers as H
+from tests.golden import cases
+from xnrs_amd import hip, synth
+from xnrs_amd.models.components import layers, news_encoding
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+# (S, D, h, E, n_news)
+SHAPES = [
+    (30, 320, 16, 256, 33), (30, 300, 15, 256, 17), (32, 320, 16, 64, 8), (17, 320, 16, 256, 5), (16, 300, 15, 32, 4),
+    (1, 32, 4, 16, 3), (5, 16, 4, 16, 7), (8, 32, 4, 16, 6), (20, 48, 4, 16, 9), (30, 64, 4, 32, 11), (25, 96, 4, 32, 2),
+    (31, 224, 8, 64, 5), (9, 128, 4, 32, 1), (30, 256, 16, 256, 21), (12, 320, 10, 64, 3), (30, 240, 12, 48, 10),
+]
+
+
+def build(S, D, h, E, seed):
+    enc = news_encoding.TextEncoder(pooler=layers.AdditiveAttention(D, 256), p_dropout=0.0, out_features=E, in_features=D,
+                                    head=True, att=layers.MultiHeadAttention(h, D), bias=True)
+    shapes = {k: tuple(v.shape) for k, v in enc.state_dict().items()}
+    sd = synth.fill_state_dict(shapes, seed)
+    enc.load_state_dict(sd)
+    return enc.eval().to(DEV), sd
+
+
+def stages_used(fn):
+    hip.profile_enable(0x7F)
+    out = fn()
+    torch.cuda.synchronize()
+    st = hip.profile_read()
+    hip.profile_enable(0)
+    return out, {k for k, v in st.items() if v[1] > 0}
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "S%d_D%d_h%d_E%d_n%d" % s)
+def test_fused_equals_oracle_and_unfused(shape):
+    S, D, h, E, n = shape
+    enc, sd = build(S, D, h, E, 7000 + S + D)
+    rng = synth.rng_for(8000 + S * 7 + D)
+    x, m = synth.token_block(rng, 1, n, S, D, min_len=1, full_pad_prob=0.2)
+    xd, md = x.to(DEV), m.to(DEV)
+    with torch.no_grad():
+        (y, hm), used = stages_used(lambda: enc((xd, md)))
+        assert "news_fused" in used and not (used & {"qkv_gemm", "attention_core", "out_gemm", "fc1_tanh_gemm", "pool"}), used
+        with hip.knobs(XNRS_NEWS_FUSED="0"):
+            (y0, hm0), used0 = stages_used(lambda: enc((xd, md)))
+        assert "news_fused" not in used0 and "qkv_gemm" in used0
+        yo, hmo = O.text_encoder(x, m, sd, h)
+    H.assert_close(y, yo, what="fused vs oracle")
+    H.assert_close(y, y0, tol=2e-5, what="fused vs six-launch pipeline")
+    assert torch.equal(hm, hm0) and torch.equal(hm.cpu(), hmo)
+
+
+def test_fused_with_id_gather_is_bitwise_the_materialised_gather():
+    S, D, h, E = 30, 320, 16, 256
+    enc, _ = build(S, D, h, E, 7100)
+    rng = synth.rng_for(8100)
+    tx, tm = synth.token_block(rng, 1, 40, S, D, min_len=3)
+    tx, tm = tx.reshape(40, S, D).to(DEV), tm.reshape(40, S).to(DEV)
+    ids = torch.from_numpy(rng.integers(0, 40, size=(3, 9)).astype(np.int32)).to(DEV)
+    with torch.no_grad():
+        (y, hm), used = stages_used(lambda: enc.forward_ids(tx, tm, ids))
+        assert "news_fused" in used
+        g = ids.long()
+        y1, hm1 = enc((tx[g], tm[g].unsqueeze(-1)))
+    assert torch.equal(y, y1) and torch.equal(hm, hm1)
+
+
+def test_row_mask_quirk_survives_the_fusion():
+    """layers.py:142-144 masks QUERY rows: a padded key still receives attention from valid rows, so changing the
+    token vector at a padded position must change the output (it would not under a key mask)."""
+    S, D, h, E = 30, 320, 16, 256
+    enc, sd = build(S, D, h, E, 7200)
+    rng = synth.rng_for(8200)
+    x, m = synth.token_block(rng, 1, 4, S, D, min_len=5)
+    m[0, 0, 20:] = 0
+    x2 = x.clone()
+    x2[0, 0, 25] += 1.0  # a padded position of news 0
+    with torch.no_grad():
+        y, _ = enc((x.to(DEV), m.to(DEV)))
+        y2, _ = enc((x2.to(DEV), m.to(DEV)))
+        yo2, _ = O.text_encoder(x2, m, sd, h)
+    assert (y2[0, 0] - y[0, 0]).abs().max().item() > 1e-4
+    assert torch.equal(y2[0, 1:], y[0, 1:])
+    H.assert_close(y2, yo2, what="perturbed pad token vs oracle")
+
+
+def test_shapes_outside_the_fused_range_take_the_pipeline():
+    for (S, D, h) in ((33, 320, 16), (30, 768, 16), (30, 36, 6)):  # S > 32, D > 320, d_k % 4 != 0
+        enc, sd = build(S, D, h, 32, 7300 + S)
+        rng = synth.rng_for(8300 + D)
+        x, m = synth.token_block(rng, 1, 3, S, D, min_len=2)
+        with torch.no_grad():
+            (y, _), used = stages_used(lambda: enc((x.to(DEV), m.to(DEV))))
+            yo, _ = O.text_encoder(x, m, sd, h)
+        assert "news_fused" not in used and "qkv_gemm" in used
+        H.assert_close(y, yo, what=f"pipeline S={S} D={D}")
+
+
+def test_large_batch_properties_at_configs1():
+    """1024 news x 30 tokens x 320 (BASELINE configs[1]): permutation equivariance over news and independence of the
+    batch (a news encodes to the same bits alone, in a pair, or among 1024)."""
+    S, D, h, E, n = 30, 320, 16, 256, 1024
+    enc, _ = build(S, D, h, E, 7400)
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(3)
+    x, m = synth.device_tokens(gen, n, S, D, DEV)
+    x, m = x.reshape(1, n, S, D), m.reshape(1, n, S, 1)
+    perm = torch.randperm(n, device=DEV)
+    with torch.no_grad():
+        y, hm = enc((x, m))
+        yp, _ = enc((x[:, perm], m[:, perm]))
+        y1, _ = enc((x[:, 5:6], m[:, 5:6]))
+        y2, _ = enc((x[:, 4:6], m[:, 4:6]))
+    assert torch.isfinite(y).all()
+    assert torch.equal(yp, y[:, perm])
+    assert torch.equal(y1[0, 0], y[0, 5]) and torch.equal(y2[0, 1], y[0, 5])

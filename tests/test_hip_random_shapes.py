@@ -94,11 +94,13 @@ def test_random_bi_encoder_matches_oracle(seed):
     # the fp32-grade split mode on every forward GEMM
     prev = hip.set_gemm_mode(hip.GEMM_BF16X3)
     os.environ["XNRS_GEMM_SPLIT_MIN_TILES"] = "0"
+    hip.reload_knobs()
     try:
         r3, _, c3 = run()
     finally:
         hip.set_gemm_mode(prev)
         os.environ.pop("XNRS_GEMM_SPLIT_MIN_TILES", None)
+        hip.reload_knobs()
     H.assert_close(c3, cv, what=what + " bf16x3 cand")
     H.assert_close(r3, ref, what=what + " bf16x3 scores")
 

@@ -28,12 +28,14 @@ def split_mode():
     prev = hip.get_gemm_mode()
     old = os.environ.get("XNRS_GEMM_SPLIT_MIN_TILES")
     os.environ["XNRS_GEMM_SPLIT_MIN_TILES"] = "0"
+    hip.reload_knobs()
     yield hip.set_gemm_mode
     hip.set_gemm_mode(prev)
     if old is None:
         os.environ.pop("XNRS_GEMM_SPLIT_MIN_TILES", None)
     else:
         os.environ["XNRS_GEMM_SPLIT_MIN_TILES"] = old
+    hip.reload_knobs()
 
 
 def _fp64_err(y, x, w, b, act):
@@ -151,6 +153,7 @@ def test_benchmark_shape_scores_under_split(split_mode):
         split_mode(0)
         r0 = bench.step(model, hist, cand)
         os.environ.pop("XNRS_GEMM_SPLIT_MIN_TILES", None)  # the shipping dispatch rule
+        hip.reload_knobs()
         split_mode(1)
         r1 = bench.step(model, hist, cand)
         split_mode(2)

@@ -35,6 +35,7 @@ for (M, N, K) in shapes:
             for k in ALL_KEYS:
                 os.environ.pop(k, None)
             os.environ.update({k: e for k, e in env.items() if k != "MODE"})
+            hip.reload_knobs()  # the library reads its knobs at load and on request only
             hip.set_gemm_mode(int(env.get("MODE", 0)))  # "MODE=1|2": the bf16-split kernels
             y = ops.linear(x, w, b)  # warm
             if rnd == 0:

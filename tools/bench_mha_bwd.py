@@ -8,6 +8,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from xnrs_amd import hip  # noqa: E402
 from xnrs_amd.models.components import layers  # noqa: E402
 
 dev = torch.device("cuda", 0)
@@ -22,6 +23,7 @@ for (n, S, D, h) in shapes:
     for rnd in range(3):
         for flag in ("1", "0"):
             os.environ["XNRS_MHA_BWD_FUSED"] = flag
+            hip.reload_knobs()  # the library reads its knobs at load and on request only
             for _ in range(2):
                 att.zero_grad(set_to_none=True)
                 (att(x, m) * w).sum().backward()

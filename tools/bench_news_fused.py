@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""BASELINE configs[1]: NRMS news encoder only, 1024 news x 30 tokens -- the fused short-title kernel
+(news_fused.hip) against the six-launch pipeline (XNRS_NEWS_FUSED=0), interleaved rounds in one process."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from xnrs_amd import hip, synth  # noqa: E402
+
+dev = torch.device("cuda", 0)
+n_news = int(os.environ.get("N_NEWS", "1024"))
+for (S, D, h) in ((30, 300, 15), (30, 320, 16), (20, 320, 16), (32, 320, 16)):
+    w = dict(B=1, H=1, C=1, S=S, D=D, h=h, E=256 if D != 300 else 240, A=256)
+    model, _ = bench.build_model(w, dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    x, m = synth.device_tokens(gen, n_news, S, D, dev)
+    x, m = x.reshape(1, n_news, S, D), m.reshape(1, n_news, S, 1)
+    fl = n_news * bench.news_flops(S, D, 256, w["E"])
+    res = {"1": [], "0": []}
+    with torch.no_grad():
+        for rnd in range(5):
+            for flag in ("1", "0"):
+                with hip.knobs(XNRS_NEWS_FUSED=flag):
+                    for _ in range(5):
+                        model.news_encoder((x, m))
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(20):
+                        model.news_encoder((x, m))
+                    torch.cuda.synchronize()
+                    res[flag].append((time.perf_counter() - t0) / 20)
+        with hip.knobs(XNRS_NEWS_FUSED="1"):
+            hip.profile_enable(0x7F)
+            for _ in range(10):
+                model.news_encoder((x, m))
+            torch.cuda.synchronize()
+            st = hip.profile_read()
+            hip.profile_enable(0)
+    f, u = sorted(res["1"])[2], sorted(res["0"])[2]
+    kms = st["news_fused"][0] / max(st["news_fused"][1], 1)
+    print(f"S={S} D={D} h={h} n={n_news}: fused {f*1e6:.1f} us ({fl/f/1e12:.1f} TF, {fl/f/1e12/157.3:.3f} of fp32 MFMA peak; "
+          f"kernel alone {kms*1e3:.1f} us)  pipeline {u*1e6:.1f} us ({fl/u/1e12:.1f} TF)", flush=True)

@@ -32,6 +32,7 @@ with torch.no_grad():
             for k in all_keys:
                 os.environ.pop(k, None)
             os.environ.update(env)
+            hip.reload_knobs()  # the library reads its knobs at load and on request only
             for _ in range(2):
                 model.news_encoder((x, m))
             torch.cuda.synchronize()

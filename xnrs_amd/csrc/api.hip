@@ -1,6 +1,9 @@
 // extern "C" entry points of libxnrs_hip.so (declared in include/xnrs_hip.h) and the host-side
-// orchestration of the kernel pipeline.  No allocation, no sync, no global state: everything is
-// enqueued on the caller's stream into the caller's workspace (hipGraph-capturable).
+// orchestration of the kernel pipeline.  No allocation and no sync: everything is enqueued on the caller's
+// stream into the caller's workspace (hipGraph-capturable).  Process-global state, all of it here or in
+// gemm_f32.hip and none of it touched by a plain encode/score call: the forward-GEMM arithmetic mode
+// (xnrs_set_gemm_mode, an atomic int), the development knobs (read once at load, xnrs_reload_knobs) and the
+// optional launch timer (xnrs_profile_*, mutex-guarded, off by default).
 //
 // Sequence-encoder pipeline (TextEncoder news_encoding.py:34-60 / UserEncoder user_encoding.py:50-81),
 // per chunk of sequences:
@@ -10,7 +13,9 @@
 //   [pool]  T   = tanh(Y.W1^T + b1)                            (MFMA GEMM, tanh epilogue)
 //           p   = sum_i a_i Y_i,  a = exp(T.w2+b2)*m / (sum+1e-8)   (additive_pool)  | masked mean
 //   [head]  y   = W4 relu(W3 p + b3) + b4                      (two MFMA GEMMs over all sequences)
+// Short sequences (L <= 32, D <= 320: BASELINE configs[1]) take [att] + [pool] as ONE launch (news_fused.hip).
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 #include "../../include/xnrs_hip.h"
@@ -27,6 +32,7 @@ struct Plan {
   size_t off_qkv, off_o, off_y, off_t, off_p, off_h;
   size_t off_stats, off_a;  // training only: softmax row statistics, pooling weights
   size_t off_planes;        // bf16-split GEMM modes: pre-split weight planes (wq, wk, wv, wo, w1)
+  size_t off_nf;            // fused short-sequence encoder: fragment-ordered weight images
   size_t total;
 };
 
@@ -61,6 +67,15 @@ Plan make_plan(int64_t n_seq, int L, int D, int A, int E, bool att, bool additiv
   if (att) pl += 4 * align_up(split_planes_bytes(D, D));
   if (pooled && additive) pl += align_up(split_planes_bytes(A, D));
   p.off_planes = take((pl + 3) / 4);
+  // fused short-sequence path (news_fused.hip): reserved whenever the shape is eligible, whatever the knobs say
+  // (a size query does not know the head count: it reserves the bound over all of them)
+  NewsFusedPlan nf{};
+  size_t nfb = 0;
+  if (att && additive && !train) {
+    if (n_heads <= 0) nfb = news_fused_img_bound_bytes(L, D, A);
+    else if (news_fused_plan(L, D, n_heads, A, &nf)) nfb = nf.img_bytes;
+  }
+  p.off_nf = nfb ? take((nfb + 3) / 4) : 0;
   p.total = off;
   return p;
 }
@@ -73,8 +88,9 @@ struct ProfRec {
   int stage;
   double flops;
 };
-uint32_t g_prof_mask = 0;
+uint32_t g_prof_mask = 0;  // 0 (default): ProfScope is a single load and compare
 std::vector<ProfRec> g_prof;
+std::mutex g_prof_mu;      // guards g_prof / g_prof_mask changes; taken only while the timer is on
 constexpr size_t PROF_MAX = 1 << 16;
 
 struct ProfScope {
@@ -82,7 +98,6 @@ struct ProfScope {
   hipStream_t st;
   ProfRec r{};
   ProfScope(int stage, double flops, hipStream_t s) : on((g_prof_mask >> stage) & 1u), st(s) {
-    if (on && g_prof.size() >= PROF_MAX) on = false;
     if (!on) return;
     r.stage = stage;
     r.flops = flops;
@@ -95,7 +110,12 @@ struct ProfScope {
   ~ProfScope() {
     if (!on) return;
     (void)hipEventRecord(r.end, st);
-    g_prof.push_back(r);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof.size() < PROF_MAX) g_prof.push_back(r);
+    else {
+      (void)hipEventDestroy(r.beg);
+      (void)hipEventDestroy(r.end);
+    }
   }
 };
 
@@ -183,7 +203,28 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
     if (pooled && additive) p1 = prep(pool->w1, A, D);
   }
 
-  for (int64_t c0 = 0; c0 < n_seq; c0 += p.chunk) {
+  // Short sequences: attention + additive pooling of ALL sequences in one launch (news_fused.hip); only the pooled
+  // vectors leave the CU.  Inference only (nothing is saved for a backward), fp32 arithmetic only.
+  const bool fused = att && additive && !train && !a_out && att->dropout_p == 0.f && gemm_mode() == 0 &&
+                     knobs().news_fused && news_fused_plan(L, D, att->n_heads, A, nullptr) &&
+                     (D / att->n_heads) * att->n_heads == D;
+  if (fused) {
+    NewsFusedArgs f{};
+    f.x = x; f.ids = ids; f.mask = m;
+    f.wq = att->wq; f.bq = att->bq; f.wk = att->wk; f.bk = att->bk; f.wv = att->wv; f.bv = att->bv;
+    f.wo = att->wo; f.bo = att->bo;
+    f.w1 = pool->w1; f.b1 = pool->b1; f.w2 = pool->w2; f.b2 = pool->b2;
+    f.img = reinterpret_cast<float*>(w + p.off_nf);
+    f.p = head ? pb : y;
+    f.ldp = D;
+    f.hm = m ? hm : nullptr;
+    f.n_seq = n_seq;
+    f.S = L; f.D = D; f.n_heads = att->n_heads; f.d_k = D / att->n_heads; f.A = A; f.scaled = att->scaled;
+    const double fl = (double)n_seq * (8.0 * L * D * D + 4.0 * L * L * D + 2.0 * L * D * A + 2.0 * L * (A + D));
+    ProfScope ps(6, fl, stream);
+    XNRS_TRY(launch_news_fused(f, stream));
+  }
+  for (int64_t c0 = 0; !fused && c0 < n_seq; c0 += p.chunk) {
     const int64_t nc = (n_seq - c0 < p.chunk) ? (n_seq - c0) : p.chunk;
     const int64_t rows = nc * L;
     // this chunk's view of the inputs
@@ -543,7 +584,13 @@ int32_t xnrs_set_gemm_mode(int32_t mode) {
 
 int32_t xnrs_get_gemm_mode(void) { return xnrs::gemm_mode(); }
 
+int32_t xnrs_reload_knobs(void) {
+  xnrs::reload_knobs();
+  return XNRS_OK;
+}
+
 int32_t xnrs_profile_enable(uint32_t stage_mask) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& r : g_prof) {
     (void)hipEventDestroy(r.beg);
     (void)hipEventDestroy(r.end);
@@ -561,6 +608,7 @@ int32_t xnrs_profile_read(double* ms, int64_t* launches, double* flops) {
     flops[i] = 0.0;
   }
   int32_t rc = XNRS_OK;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& r : g_prof) {
     float t = 0.f;
     hipError_t e = hipEventSynchronize(r.end);

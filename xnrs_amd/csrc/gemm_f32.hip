@@ -9,26 +9,29 @@
 // v_mfma_f32_32x32x2_f32 is an exact fp32 fmaf chain (no TF32/xf32 on gfx950), so results differ from
 // torch-CPU only by summation order.
 //
-// Design (gfx950, 64-wide waves):
-//   * workgroup = 256 threads = 4 waves in a 2x2 grid; wave tile (32*TM)x(32*TN), i.e. the block
-//     tile is (64*TM)x(64*TN); BK = 32.
-//   * k-contiguous operands (ROW / WT): a lane fetches 4 consecutive k with ONE ds_read_b128 and feeds
-//     4 MFMA steps from it: MFMA step j of an 8-wide k group uses k = 4*(lane>>5) + j for A and B
-//     alike (any bijection of k is legal as long as A and B agree).  LDS rows padded to 36 floats:
-//     the 16-lane groups of ds_read_b128 then hit 64 distinct banks.
-//   * k-major operands (COL / KN): LDS image [k][i] (rows padded by 4), fragments are 4 ds_read_b32
-//     with the 32 lanes of a half-wave on 32 consecutive floats (conflict-free).
-//     Per 8 k: TM+TN b128 reads (or 4x as many b32) vs 4*TM*TN MFMAs of 64 cycles each.
-//   * register-staged double buffering (issue global loads for tile t+1, compute tile t, then write
-//     LDS) with one barrier per K tile; 2 workgroups/CU co-reside (<= 73.7 KB LDS each).
-//   * optional row gather on the rows of a ROW-layout A / KN-layout B (device-resident news-token
-//     table + ids: SURVEY.md section 8 a0) folded into the per-thread row pointers, so gathered rows are still
-//     read as full 128-B lines.
-//   * XCD-aware block order: the 8 XCDs each walk a contiguous range of tiles with the N tiles of
-//     one M tile adjacent, so an A tile is fetched into one L2 only.
-//   * split-K (dW: the contraction is the token-row count, the output is a small weight matrix):
-//     each k-slice writes its own fp32 slab; a second kernel sums the slabs in a fixed order
-//     (bitwise reproducible, no float atomics).
+// Design (gfx950, 64-wide waves); measurements and the dropped alternatives: DESIGN.md section 4.1
+//   * workgroup = 256 threads = 4 waves in a 2x2 grid; wave tile (32*TM)x(32*TN), i.e. the block tile is
+//     (64*TM)x(64*TN): 128x128 by default, 128x64 / 64x128 / 64x64 picked by a padded-work estimate.
+//   * k-contiguous operands (ROW / WT): a lane fetches 4 consecutive k with ONE ds_read_b128 and feeds 4 MFMA
+//     steps from it: step j of an 8-wide k group uses k = 4*(lane>>5) + j for A and B alike (any bijection of k is
+//     legal as long as A and B agree).
+//   * shipped forward configuration (template PIPE 5, BK 16, BUF, MINW 4): K tiles of 16, 64-byte LDS rows with
+//     the 16-byte chunk XOR-swizzled by (row>>2)&3 (conflict-free ds_read_b128 and ds_write_b128), two LDS buffers
+//     (32 KB), ONE register set, an explicitly interleaved instruction stream (one LDS store, one tile load and the
+//     next fragment reads behind each slot of TM*TN MFMAs, pinned by sched_barrier), raw buffer loads whose
+//     bounds check zero-fills ragged rows / k tails, registers capped at 128 -> 4 workgroups per CU.
+//     PIPE 1 (plain double buffering, BK 32, rows padded to 36 floats) serves the scalar-load fallback.
+//   * k-major operands (COL / KN, the backward's dW and small-M dX): LDS image [k][i] (rows padded by 4),
+//     fragments are 4 ds_read_b32 with the 32 lanes of a half-wave on 32 consecutive floats; PIPE 5, BK 32,
+//     2 workgroups per CU.
+//   * optional row gather on the rows of a ROW-layout A / KN-layout B (device-resident news-token table + ids:
+//     SURVEY.md section 8 a0) folded into the per-thread row offsets, so gathered rows are still read as full lines.
+//   * XCD-aware block order: each XCD walks a contiguous range of the tile sequence; column GROUPS of tiles
+//     outermost so the weight panels an XCD touches stay in its 4 MB L2.
+//   * split-K (dW: the contraction is the token-row count, the output is a small weight matrix): each k-slice
+//     writes its own fp32 slab; a second kernel sums the slabs in a fixed order (bitwise reproducible, no float
+//     atomics).
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -505,9 +508,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, 
 // column tiles per group of the tile walk (see the kernel): as many as keep the group's weight panels within
 // ~2.5 MB, evened out over the groups.  The k-major (backward) layouts keep the plain M-major walk.
 int gemm_group_tiles(int n_tiles, int bn, int64_t K, bool plain) {
-  const char* ge = getenv("XNRS_GEMM_GROUP");  // development knob: tiles per group, 0 = plain walk
   int64_t gn = (int64_t)(2.5 * 1024 * 1024) / ((int64_t)bn * (K > 0 ? K : 1) * 4);
-  if (ge) gn = atoll(ge);
+  if (knobs().gemm_group >= 0) gn = knobs().gemm_group;  // development knob: tiles per group, 0 = plain walk
   if (plain || gn <= 0 || gn >= n_tiles) return n_tiles;
   const int groups = (int)((n_tiles + gn - 1) / gn);
   return (n_tiles + groups - 1) / groups;
@@ -522,14 +524,11 @@ static hipError_t launch_cfg(const GemmArgs& a, bool vec, int nsplit, hipStream_
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
   const dim3 g((unsigned)grid, (unsigned)nsplit);
   const int gn = gemm_group_tiles(n_tiles_seg * a.nseg, BN, a.K, A_COL || B_KN);
-  // development knobs for in-process A/B runs (tools/bench_gemm.py): XNRS_GEMM_PIPE=1|5|6, XNRS_GEMM_BK=16|32,
-  // XNRS_GEMM_BUF=0|1.  Default ("6"): PIPE 5, BK 16, registers capped for 4 workgroups per CU on the main tile.
-  const char* pe = getenv("XNRS_GEMM_PIPE");
-  const char* be = getenv("XNRS_GEMM_BK");
-  const char* ue = getenv("XNRS_GEMM_BUF");
-  const int pipe = pe ? (pe[0] - '0') : 6;
-  const int bk = be ? ((be[0] == '1') ? 16 : 32) : 32;
-  const bool buf = !(ue && ue[0] == '0') && vec && !a.gather_ids && a.M * a.lda * 4 <= (int64_t)BUF_OOB &&
+  // development knobs for in-process A/B runs (tools/bench_gemm.py; kernels.h: Knobs).  Default (pipe 6): PIPE 5,
+  // BK 16, registers capped for 4 workgroups per CU on the main tile.
+  const int pipe = knobs().gemm_pipe;
+  const int bk = knobs().gemm_bk;
+  const bool buf = knobs().gemm_buf && vec && !a.gather_ids && a.M * a.lda * 4 <= (int64_t)BUF_OOB &&
                    (int64_t)a.Nseg * a.ldw * 4 <= (int64_t)BUF_OOB;
 #define XNRS_LAUNCH(VECV, PIPEV, BKV, BUFV, MINWV)                                                                  \
   hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, A_COL, B_KN, VECV, PIPEV, BKV, BUFV, MINWV>), g, dim3(256), 0, stream, a, \
@@ -579,8 +578,7 @@ static hipError_t launch_layout(const GemmArgs& a, bool vec, int nsplit, hipStre
       best = c;
     }
   }
-  const char* te = getenv("XNRS_GEMM_TILE");  // development knob: force tile candidate 0..3
-  if (te && te[0] >= '0' && te[0] <= '3') best = te[0] - '0';
+  if (knobs().gemm_tile >= 0 && knobs().gemm_tile <= 3) best = knobs().gemm_tile;  // development knob
   switch (best) {
     case 0: return launch_cfg<2, 2, A_COL, B_KN>(a, vec, nsplit, stream);
     case 1: return launch_cfg<2, 1, A_COL, B_KN>(a, vec, nsplit, stream);
@@ -606,15 +604,33 @@ int gemm_pick_splits(int64_t M, int64_t N, int64_t K) {
   return (int)ns;
 }
 
-static int g_gemm_mode = -1;
-int gemm_mode() {
-  if (g_gemm_mode < 0) {
-    const char* e = getenv("XNRS_GEMM_MODE");
-    g_gemm_mode = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 0;
-  }
-  return g_gemm_mode;
+// ---- process-global state of the library: the knobs (read once) and the forward-GEMM arithmetic mode
+static Knobs read_knobs() {
+  Knobs k;
+  auto num = [](const char* name, long long dflt) {
+    const char* e = getenv(name);
+    return (e && *e) ? atoll(e) : dflt;
+  };
+  k.gemm_pipe = (int)num("XNRS_GEMM_PIPE", 6);
+  k.gemm_bk = num("XNRS_GEMM_BK", 32) == 16 ? 16 : 32;
+  k.gemm_buf = num("XNRS_GEMM_BUF", 1) != 0;
+  k.gemm_group = num("XNRS_GEMM_GROUP", -1);
+  k.gemm_tile = (int)num("XNRS_GEMM_TILE", -1);
+  k.split_min_tiles = num("XNRS_GEMM_SPLIT_MIN_TILES", 512);
+  k.mha_lds = (int)num("XNRS_MHA_LDS", -1);
+  k.mha_headwave = num("XNRS_MHA_HEADWAVE", 1) != 0;
+  k.mha_bwd_fused = num("XNRS_MHA_BWD_FUSED", 1) != 0;
+  k.news_fused = num("XNRS_NEWS_FUSED", 1) != 0;
+  const long long m = num("XNRS_GEMM_MODE", 0);
+  k.gemm_mode_init = (m >= 0 && m <= 2) ? (int)m : 0;
+  return k;
 }
-void set_gemm_mode(int mode) { g_gemm_mode = (mode >= 0 && mode <= 2) ? mode : 0; }
+static Knobs g_knobs = read_knobs();  // at library load
+static std::atomic<int> g_gemm_mode{g_knobs.gemm_mode_init};
+const Knobs& knobs() { return g_knobs; }
+void reload_knobs() { g_knobs = read_knobs(); }
+int gemm_mode() { return g_gemm_mode.load(std::memory_order_relaxed); }
+void set_gemm_mode(int mode) { g_gemm_mode.store((mode >= 0 && mode <= 2) ? mode : 0, std::memory_order_relaxed); }
 
 hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t stream) {
   GemmArgs a = a_in;
@@ -643,8 +659,7 @@ hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t stream) {
   const int mode = gemm_mode();
   // the split kernel has one tile shape (128x128): below one full round of workgroups the fp32 kernel with its
   // smaller tiles is faster (measured: 4099 x 260 x 300 -> 38 TF fp32 vs 22 TF split)
-  const char* mte = getenv("XNRS_GEMM_SPLIT_MIN_TILES");  // tests force the split kernel onto tiny shapes with 0
-  const int64_t min_tiles = mte ? atoll(mte) : 512;
+  const int64_t min_tiles = knobs().split_min_tiles;  // tests force the split kernel onto tiny shapes with 0
   if (mode && !a.a_col && !a.b_kn && vec && nsplit == 1 &&
       ((a.M + 127) / 128) * ((a.Nseg + 127) / 128) * a.nseg >= min_tiles)
     return launch_gemm_split(a, mode == 1 ? 3 : 2, stream);

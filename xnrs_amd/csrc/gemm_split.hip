@@ -338,8 +338,7 @@ hipError_t launch_gemm_split(const GemmArgs& a, int npl, hipStream_t stream) {
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
   const dim3 g((unsigned)grid, 1);
   const int gn = gemm_group_tiles(n_tiles_seg * a.nseg, 128, a.K, false);
-  const char* ue = getenv("XNRS_GEMM_BUF");
-  const bool buf = !(ue && ue[0] == '0') && !a.gather_ids && a.M * a.lda * 4 <= (int64_t)SPLIT_OOB &&
+  const bool buf = knobs().gemm_buf && !a.gather_ids && a.M * a.lda * 4 <= (int64_t)SPLIT_OOB &&
                    (int64_t)a.Nseg * a.ldw * 4 <= (int64_t)SPLIT_OOB;
 #define XNRS_LAUNCH_SPLIT(NPLV, BUFV, MINWV) \
   hipLaunchKernelGGL((gemm_split_kernel<NPLV, BUFV, MINWV>), g, dim3(256), 0, stream, a, (int)m_tiles, n_tiles_seg, gn)

@@ -9,6 +9,27 @@ namespace xnrs {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// ---------------------------------------------------------------- development knobs
+// Kernel-selection switches for in-process A/B runs (tools/) and tests.  They are read from the XNRS_* environment
+// ONCE, when the library is loaded, and again only on xnrs_reload_knobs() (C ABI): the launch path never calls
+// getenv.  Process-global and deliberately not synchronised -- do not reload while another thread is launching.
+// None of them changes a result beyond summation order.
+struct Knobs {
+  int gemm_pipe = 6;            // XNRS_GEMM_PIPE=1|5 force a software pipeline; 6 = the shipped configuration
+  int gemm_bk = 32;             // XNRS_GEMM_BK=16|32 (with XNRS_GEMM_PIPE=5)
+  int gemm_buf = 1;             // XNRS_GEMM_BUF=0: no raw buffer loads
+  long long gemm_group = -1;    // XNRS_GEMM_GROUP=n column tiles per walk group (0 = plain walk); -1 = automatic
+  int gemm_tile = -1;           // XNRS_GEMM_TILE=0..3 force a block tile; -1 = cost model
+  long long split_min_tiles = 512;  // XNRS_GEMM_SPLIT_MIN_TILES: smallest launch the bf16-split kernel takes
+  int mha_lds = -1;             // XNRS_MHA_LDS=0|1 force / forbid the LDS-staged attention kernel; -1 = by shape
+  int mha_headwave = 1;         // XNRS_MHA_HEADWAVE=0: generic attention kernel only
+  int mha_bwd_fused = 1;        // XNRS_MHA_BWD_FUSED=0: two-kernel attention backward
+  int news_fused = 1;           // XNRS_NEWS_FUSED=0: never use the fused short-title news encoder (news_fused.hip)
+  int gemm_mode_init = 0;       // XNRS_GEMM_MODE=0|1|2: initial forward-GEMM arithmetic (see gemm_mode())
+};
+const Knobs& knobs();
+void reload_knobs();
+
 // ---------------------------------------------------------------- Linear (fp32 MFMA GEMM)
 // C[M, nseg*Nseg] = act(A[M,K] . W_s[Nseg,K]^T + bias_s), s = column segment (up to 3 weights
 // side by side: the Q/K/V projections share one launch while the parameters stay separate
@@ -63,8 +84,9 @@ hipError_t launch_gemm_split(const GemmArgs& a, int npl, hipStream_t stream);
 inline int64_t split_plane_ld(int64_t K) { return (K + 15) / 16 * 16; }
 inline size_t split_planes_bytes(int64_t N, int64_t K) { return (size_t)3 * (size_t)N * (size_t)split_plane_ld(K) * 2; }
 hipError_t launch_split_weights(const float* W, int64_t N, int64_t K, unsigned short* planes, hipStream_t stream);
-// 0: exact fp32 MFMA (default); 1: bf16x3 split, six products (fp32-grade); 2: bf16x2 split, three products.
-// Initialised from XNRS_GEMM_MODE; applies to the forward (ROW x WT) layout only.
+// 0: exact fp32 MFMA (default); 1: bf16x3 split, six products; 2: bf16x2 split, three products.  Applies to the
+// forward (ROW x WT) layout only.  PROCESS-GLOBAL (one relaxed atomic int, initialised from XNRS_GEMM_MODE when the
+// library is loaded): every later launch from any thread uses the mode set last.
 int gemm_mode();
 void set_gemm_mode(int mode);
 
@@ -141,6 +163,32 @@ __device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
   z = z ^ (z >> 31);
   return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
+
+// ---------------------------------------------------------------- fused news encoder, S <= 32 tokens (news_fused.hip)
+// att -> additive pooler of TextEncoder.forward in ONE launch (news_encoding.py:48-54, layers.py:60-65,128-154)
+struct NewsFusedArgs {
+  const float* x;      // [n_seq, S, D] token rows, or the table when ids != null
+  const int32_t* ids;  // nullable: news n is table row ids[n] (x and mask are then the table's)
+  const float* mask;   // [n_seq, S] fp32 0/1 (or table mask), nullable
+  const float *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo;  // nn.Linear layout [out][in]; biases nullable
+  const float *w1, *b1, *w2, *b2;                        // fc1 [A][D], fc2 [A]
+  float* img;          // workspace of NewsFusedPlan::img_bytes: the weights in MFMA fragment order (built per call)
+  float* p;            // [n_seq, ldp] pooled vectors
+  int64_t ldp;
+  float* hm;           // nullable [n_seq]: clamp(sum mask, 0, 1)
+  int64_t n_seq;
+  int32_t S, D, n_heads, d_k, A, scaled;
+};
+struct NewsFusedPlan {
+  int npw, hg, lq, ly;  // news per workgroup, heads per group, LDS row strides of the Q|K|V and Y images
+  int n_groups, nk, nkc;  // head groups, 16-wide k steps of D, of one group's hg * d_k attention-output columns
+  size_t lds_bytes;
+  size_t img_bytes;       // caller-provided workspace for the fragment-ordered weight images
+};
+// does the fused kernel cover this shape (and with which plan)?
+bool news_fused_plan(int S, int D, int n_heads, int A, NewsFusedPlan* plan);
+size_t news_fused_img_bound_bytes(int S, int D, int A);  // >= img_bytes for every n_heads; 0: no head count is eligible
+hipError_t launch_news_fused(const NewsFusedArgs& a, hipStream_t stream);
 
 // ---------------------------------------------------------------- pooling / scoring
 struct AdditivePoolArgs {

@@ -502,8 +502,7 @@ hipError_t launch_mha_bwd(const MhaBwdArgs& a, hipStream_t stream) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const int KT = (a.S + 15) / 16;
-  const char* fe = getenv("XNRS_MHA_BWD_FUSED");  // development knob for A/B runs; default on
-  if (vec && a.S <= 64 && a.d_k <= 64 && !(fe && fe[0] == '0')) {
+  if (vec && a.S <= 64 && a.d_k <= 64 && knobs().mha_bwd_fused) {  // development knob for A/B runs; default on
     const int64_t n_pairs = a.n_seq * a.n_heads;
     if (n_pairs > 0x7fffffffLL) return hipErrorInvalidValue;
     const dim3 fgrid((unsigned)n_pairs);

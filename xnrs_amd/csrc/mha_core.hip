@@ -498,12 +498,11 @@ hipError_t launch_mha_core(const MhaCoreArgs& a, hipStream_t stream) {
                    ((reinterpret_cast<uintptr_t>(a.q) & 15) == 0) && ((reinterpret_cast<uintptr_t>(a.k) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0);
   const int KT = (a.S + 15) / 16;
-  const char* fe = getenv("XNRS_MHA_HEADWAVE");  // development knob for A/B runs; default on
-  const bool fast = vec && a.S <= 64 && a.d_k <= 64 && ((int64_t)a.S * a.ld < (1ll << 31)) && !(fe && fe[0] == '0');
+  // knobs().mha_headwave / mha_lds: development knobs for A/B runs
+  const bool fast = vec && a.S <= 64 && a.d_k <= 64 && ((int64_t)a.S * a.ld < (1ll << 31)) && knobs().mha_headwave;
   // three or four query tiles: LDS-staged kernel (one wave per tile, K/V shared through LDS; 0.99 vs 1.06 ms
   // at S=50); one or two tiles: head-per-wave kernel (0.17 vs 0.21 ms at S=30).  XNRS_MHA_LDS=0|1 forces one.
-  const char* le = getenv("XNRS_MHA_LDS");
-  const bool use_lds = a.q_off ? true : (le ? (le[0] != '0') : (KT >= 3));
+  const bool use_lds = a.q_off ? true : (knobs().mha_lds >= 0 ? knobs().mha_lds != 0 : (KT >= 3));
   if (a.q_off && (!fast || a.stats || a.dropout_p > 0.f || a.ldq % 4 != 0)) return hipErrorInvalidValue;
   if (fast && use_lds) {
     switch (KT) {

@@ -1,0 +1,603 @@
+// Fused news encoder for short titles (S <= 32 tokens): ONE launch (plus a weight-reordering prologue) for
+//   TextEncoder.forward   xnrs/models/components/news_encoding.py:48-54   (att -> pooler; the MLP head stays a GEMM pair)
+//   MultiHeadAttention    xnrs/models/components/layers.py:128-154        (Q/K/V projection, row-masked softmax, PV, out)
+//   AdditiveAttention     xnrs/models/components/layers.py:60-65          (fc1, tanh, fc2, exp, mask, normalise, sum)
+// BASELINE configs[1] (1024 news x 30 tokens, D = 300 / 320): the six-launch pipeline of api.hip runs at 0.50-0.54
+// of the fp32 matrix peak there because every stage is a few dozen microseconds of partially filled tiles.
+//
+// Decomposition.  A workgroup of 8 waves owns one CU and NPW = 2 news = 4 tiles of 16 token rows, and keeps them on
+// the CU from the token rows to the pooled vector.  Everything is computed TRANSPOSED -- out^T[feature][row] = W .
+// act^T -- with v_mfma_f32_16x16x4_f32: the weight rows are the MFMA's A operand, the token rows its B operand, so
+//   * both operands are 16-byte fragments of 4 consecutive k (lane (c, g): row c, k = 4g .. 4g+3; MFMA step j uses
+//     k = 4g + j on both sides);
+//   * an accumulator holds 4 consecutive FEATURES of one token row per lane -> one ds_write_b128 into a row-major
+//     [row][feature] LDS image, which is exactly what the next product reads back as its B fragments;
+//   * the waves split the OUTPUT FEATURES of each product in 16-feature tiles (Q/K/V projection and fc1: 8 ways x all
+//     4 row tiles; out-projection: 4 ways x the 2 row tiles of one news, so that its 20 tiles at D = 320 divide evenly).
+//
+// Weights (4 D^2 + A D floats, 2 MB at D = 320) are the same for every workgroup and stay L2-resident.  A prologue
+// kernel (news_fused_prep_kernel, ~2 MB written, a few microseconds per call -- the ABI keeps no state between calls)
+// rewrites them into MFMA FRAGMENT ORDER, zero padded: image[k step][wave][tile][lane][4] holds exactly the 16 bytes
+// lane `lane` feeds to the four MFMAs of that (k step, tile), so a weight fragment load is one fully coalesced 1-KB
+// read at a wave-uniform address + 16 * lane: no per-lane row pointers, no k-tail / feature-tail selects, no address
+// arithmetic in the k loops.  (The first version -- 4 waves, 16 rows x 64 B per load through 64-bit row pointers,
+// token rows re-read from global by every wave and head group -- issued 2.5 VALU instructions per MFMA, pulled
+// 2.5 GB through L2 per 1024 news and left the matrix pipe 50 % idle: profiles/r02_news_fused_v1_pmc.txt.)
+// The fragments of k step ks+1 are loaded before the MFMAs of step ks (two register sets): MFMA arbitration between
+// the waves of a SIMD is fair, so they finish a burst together and, without the prefetch, wait for memory together.
+//
+// LDS (<= 160 KB, one workgroup per CU):
+//   R1 [rows][LY]  the token rows X (read from HBM once, coalesced; optionally gathered by news id), later Y
+//   R2 [rows][LQ]  the Q|K|V columns of ONE GROUP of heads (4 heads of 20 at D = 320)
+// Per group: project (B fragments from R1) -> per (news, head) softmax(rowmask(K Q^T)) and V^T P^T with P in registers
+// (same arithmetic as mha_core.hip), O overwrites Q in place -> the out-projection accumulates the group's columns of
+// Wo into Y^T accumulators that live in registers across the groups (40 VGPRs).  Then Y + bo -> R1, fc1 + tanh with
+// the fc2 dot product taken straight from the accumulators (T never exists in memory), exp * mask / (sum + 1e-8) and
+// the weighted sum of the Y rows.
+#include <mutex>
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace xnrs {
+
+namespace {
+
+constexpr int NF_NPW = 2;     // news per workgroup
+constexpr int NF_TR = 4;      // 16-row tiles per workgroup (32 virtual rows per news)
+constexpr int NF_TF = 2;      // Q/K/V projection: 16-feature tiles per wave, 8 waves  (<= 256 columns per head group)
+constexpr int NF_TY = 5;      // out-projection: tiles per wave, 4 feature waves x 2 row waves  (D <= 320)
+constexpr int NF_TA = 2;      // fc1: tiles per wave, 8 waves  (A <= 256)
+constexpr int NF_FRAG = 256;  // floats of one (k step, tile) weight fragment: 64 lanes x 4
+constexpr int NF_THREADS = 512;
+
+template <int N>
+using IC = std::integral_constant<int, N>;
+
+// offsets (floats) of the fragment-ordered images inside the prepared-weight workspace
+struct NfImg {
+  int n_groups, nk, nkc;
+  __host__ __device__ size_t qkv_stride() const { return (size_t)nk * 8 * NF_TF * NF_FRAG; }
+  __host__ __device__ size_t wo_stride() const { return (size_t)nkc * 4 * NF_TY * NF_FRAG; }
+  __host__ __device__ size_t off_qkv(int g) const { return (size_t)g * qkv_stride(); }
+  __host__ __device__ size_t off_wo(int g) const { return (size_t)n_groups * qkv_stride() + (size_t)g * wo_stride(); }
+  __host__ __device__ size_t off_w1() const { return off_wo(n_groups); }
+  __host__ __device__ size_t off_bqkv(int g) const { return off_w1() + (size_t)nk * 8 * NF_TA * NF_FRAG + (size_t)g * 8 * NF_TF * 16; }
+  __host__ __device__ size_t off_bo() const { return off_bqkv(n_groups); }
+  __host__ __device__ size_t off_b1() const { return off_bo() + 4 * NF_TY * 16; }
+  __host__ __device__ size_t off_w2() const { return off_b1() + 8 * NF_TA * 16; }
+  __host__ __device__ size_t total() const { return off_w2() + 8 * NF_TA * 16; }
+};
+
+// image[ks][wave][t][lane][j] = W[16 (wave + NWAVE t) + (lane & 15)][16 ks + 4 (lane >> 4) + j], zero outside W
+// (NWAVE = 8 for the Q|K|V and fc1 images, 4 for the out-projection image)
+__global__ __launch_bounds__(256) void news_fused_prep_kernel(NewsFusedArgs a, NfImg im, int HG, float* img) {
+  const int D = a.D, dk = a.d_k, H = a.n_heads, A = a.A;
+  const size_t n4 = im.off_bqkv(0) / 4;  // float4 slots of the three weight images
+  const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i4 < n4) {
+    const size_t e = i4 * 4;
+    const int lane = (int)(i4 & 63), c = lane & 15, g4 = lane >> 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (e < im.off_wo(0)) {  // Q|K|V columns of a head group
+      const int grp = (int)(e / im.qkv_stride());
+      size_t r = (e - (size_t)grp * im.qkv_stride()) / NF_FRAG;  // (ks * 8 + wave) * TF + t
+      const int t = (int)(r % NF_TF);
+      r /= NF_TF;
+      const int w = (int)(r & 7), ks = (int)(r >> 3);
+      const int h0 = grp * HG, nh = (H - h0 < HG) ? H - h0 : HG, NW = nh * dk;
+      const int f = 16 * (w + 8 * t) + c, k = 16 * ks + 4 * g4;
+      if (f < 3 * NW && k < D) {
+        const int seg = f / NW, wi = f - seg * NW;
+        const float* Ws = seg == 0 ? a.wq : (seg == 1 ? a.wk : a.wv);
+        v = *reinterpret_cast<const f32x4*>(Ws + (size_t)(h0 * dk + wi) * D + k);
+      }
+    } else if (e < im.off_w1()) {  // this group's d_k * nh columns of Wo
+      const size_t e2 = e - im.off_wo(0);
+      const int grp = (int)(e2 / im.wo_stride());
+      size_t r = (e2 - (size_t)grp * im.wo_stride()) / NF_FRAG;  // (ks * 4 + wf) * TY + t
+      const int t = (int)(r % NF_TY);
+      r /= NF_TY;
+      const int w = (int)(r & 3), ks = (int)(r >> 2);
+      const int h0 = grp * HG, nh = (H - h0 < HG) ? H - h0 : HG, NW = nh * dk;
+      const int d = 16 * (w + 4 * t) + c, k = 16 * ks + 4 * g4;
+      if (d < D && k < NW) v = *reinterpret_cast<const f32x4*>(a.wo + (size_t)d * D + h0 * dk + k);
+    } else {  // fc1
+      size_t r = (e - im.off_w1()) / NF_FRAG;  // (ks * 8 + wave) * TA + t
+      const int t = (int)(r % NF_TA);
+      r /= NF_TA;
+      const int w = (int)(r & 7), ks = (int)(r >> 3);
+      const int ar = 16 * (w + 8 * t) + c, k = 16 * ks + 4 * g4;
+      if (ar < A && k < D) v = *reinterpret_cast<const f32x4*>(a.w1 + (size_t)ar * D + k);
+    }
+    *reinterpret_cast<f32x4*>(img + e) = v;
+    return;
+  }
+  // bias / fc2 images: [wave][t][16], element i = vector[16 (wave + NWAVE t) + i] or 0
+  const size_t e = (i4 - n4) * 4 + im.off_bqkv(0);
+  if (e >= im.total()) return;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  auto pick = [&](size_t rel, int T, int nwave, const float* src, int n) {
+    const int i0 = (int)(rel & 15);
+    const int t = (int)((rel >> 4) % T), w = (int)((rel >> 4) / T);
+    const int f = 16 * (w + nwave * t) + i0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (src && f + r < n) ? src[f + r] : 0.f;
+  };
+  if (e < im.off_bo()) {
+    const size_t rel0 = e - im.off_bqkv(0);
+    const int grp = (int)(rel0 / (8 * NF_TF * 16));
+    const int h0 = grp * HG, nh = (H - h0 < HG) ? H - h0 : HG, NW = nh * dk;
+    const size_t rel = rel0 - (size_t)grp * 8 * NF_TF * 16;
+    const int f = 16 * ((int)((rel >> 4) / NF_TF) + 8 * (int)((rel >> 4) % NF_TF)) + (int)(rel & 15);
+    if (f < 3 * NW) {  // four consecutive features never straddle a segment (NW % 4 == 0)
+      const int seg = f / NW, wi = f - seg * NW;
+      const float* bs = seg == 0 ? a.bq : (seg == 1 ? a.bk : a.bv);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = bs ? bs[h0 * dk + wi + r] : 0.f;
+    }
+  } else if (e < im.off_b1()) {
+    pick(e - im.off_bo(), NF_TY, 4, a.bo, D);
+  } else if (e < im.off_w2()) {
+    pick(e - im.off_b1(), NF_TA, 8, a.b1, A);
+  } else {
+    pick(e - im.off_w2(), NF_TA, 8, a.w2, A);
+  }
+  *reinterpret_cast<f32x4*>(img + e) = v;
+}
+
+// k loop of the three big products: two fragment register sets, the loads of step ks+1 are issued before the MFMAs
+// of step ks
+#define NF_KLOOP(NK)                                 \
+  load(IC<0>{}, 0);                                  \
+  for (int ks = 0; ks < (NK); ks += 2) {             \
+    if (ks + 1 < (NK)) load(IC<1>{}, ks + 1);        \
+    mma(IC<0>{});                                    \
+    if (ks + 1 < (NK)) {                             \
+      if (ks + 2 < (NK)) load(IC<0>{}, ks + 2);      \
+      mma(IC<1>{});                                  \
+    }                                                \
+  }
+
+template <int DK4>
+__global__ __launch_bounds__(NF_THREADS, 2) void news_fused_kernel(NewsFusedArgs a, NfImg im, const float* __restrict__ img, int HG,
+                                                                   int LQ, int LY) {
+  constexpr int NPW = NF_NPW, TR = NF_TR, TF = NF_TF, TY = NF_TY, TA = NF_TA;
+  constexpr int dk = 4 * DK4;  // head width: compile-time, so the attention core is one straight run of MFMAs
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int S = a.S, D = a.D, H = a.n_heads;
+  const int nrow = NPW * S;
+  float* r1 = smem;                      // X, later Y: [nrow][LY]
+  float* r2 = r1 + nrow * LY;            // Q|K|V of a head group: [nrow][LQ]
+  float* epart = r2 + nrow * LQ;         // [8 waves][NPW * 32] partial fc2 scores
+  float* aw = epart + 8 * NPW * 32;      // [NPW * 32] un-normalised pooling weights
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wf = wave & 3, wr = wave >> 2;  // out-projection: feature quarter, news
+  const int c = lane & 15, g = lane >> 4;
+  const int64_t news0 = (int64_t)blockIdx.x * NPW;
+
+  // ---- token rows -> R1, coalesced 16-byte chunks.  A news past the end of the batch is a duplicate of the last one
+  // (computed, never stored), so no uninitialised LDS is ever read.
+  {
+    const int cpr = D >> 2;  // 16-byte chunks per row
+    for (int i = tid; i < nrow * cpr; i += NF_THREADS) {
+      const int row = i / cpr, ch = i - row * cpr;
+      const int nw = row / S, s = row - nw * S;
+      int64_t news = news0 + nw;
+      if (news >= a.n_seq) news = a.n_seq - 1;
+      const int64_t src = a.ids ? (int64_t)a.ids[news] : news;
+      *reinterpret_cast<f32x4*>(&r1[row * LY + 4 * ch]) =
+          __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.x + (src * S + s) * (int64_t)D + 4 * ch));
+    }
+  }
+
+  // ---- this lane's token row in each row tile: news nw = rt >> 1 owns the virtual rows 32 nw .. 32 nw + 31; rows
+  // >= S (tile padding) are clamped duplicates -- every product treats token rows independently -- and only their
+  // stores are predicated
+  int prow[TR];
+  bool lds_ok[TR];
+#pragma unroll
+  for (int rt = 0; rt < TR; ++rt) {
+    const int sp = (rt & 1) * 16 + c;
+    lds_ok[rt] = sp < S;
+    prow[rt] = (rt >> 1) * S + (sp < S ? sp : S - 1);
+  }
+  // the two row tiles of news `wr` (out-projection)
+  int prow_c[2];
+  bool ok_c[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int sp = i * 16 + c;
+    ok_c[i] = sp < S;
+    prow_c[i] = wr * S + (sp < S ? sp : S - 1);
+  }
+
+  f32x4 yacc[TY][2];
+#pragma unroll
+  for (int t = 0; t < TY; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) yacc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = im.nk;
+  const float* imgl = img + lane * 4;  // this lane's 16 bytes of every weight fragment
+  const float inv_sq = a.scaled ? 1.f / sqrtf((float)dk) : 1.f;
+  const int KT = (S + 15) >> 4;
+  constexpr int nfull = dk >> 4, nrem = (dk & 15) >> 2, ndt = (dk + 15) >> 4;
+  __syncthreads();  // X is in R1
+
+  const int n_groups = im.n_groups;
+  for (int grp = 0; grp < n_groups; ++grp) {
+    const int h0 = grp * HG;
+    const int nh = (H - h0 < HG) ? H - h0 : HG;
+    const int NW = nh * dk;  // width of each of the Q, K, V column blocks of this group
+    const int NF = 3 * NW;
+
+    // ================= (a) Q|K|V columns of the group: out^T[f][row] = W_f . x_row (+ bias) -> R2
+    // Every wave computes the same COMPILE-TIME number of tiles (tile t of wave w is tile w + 8 t); a tile past the
+    // end of the product is all zeros in the image and its result is dropped (1 tile of 16 at D = 320): no branches
+    // in the k loop.
+    {
+      const float* wa = imgl + im.off_qkv(grp) + (size_t)wave * TF * NF_FRAG;
+      f32x4 acc[TF][TR];
+#pragma unroll
+      for (int t = 0; t < TF; ++t)
+#pragma unroll
+        for (int rt = 0; rt < TR; ++rt) acc[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 fa[2][TF], fb[2][TR];
+      auto load = [&](auto ST, int ks) {
+        constexpr int st = decltype(ST)::value;
+        int kc = ks * 16 + 4 * g;
+        if (kc > D - 4) kc = D - 4;  // k tail: the weight image is zero there, the read only has to stay inside the row
+        const float* wk = wa + (size_t)ks * (8 * TF * NF_FRAG);
+#pragma unroll
+        for (int t = 0; t < TF; ++t) fa[st][t] = *reinterpret_cast<const f32x4*>(wk + t * NF_FRAG);
+#pragma unroll
+        for (int rt = 0; rt < TR; ++rt) fb[st][rt] = *reinterpret_cast<const f32x4*>(&r1[prow[rt] * LY + kc]);
+      };
+      auto mma = [&](auto ST) {
+        constexpr int st = decltype(ST)::value;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int t = 0; t < TF; ++t)
+#pragma unroll
+            for (int rt = 0; rt < TR; ++rt)
+              acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[st][t][j], fb[st][rt][j], acc[t][rt], 0, 0, 0);
+      };
+      NF_KLOOP(nk)
+      // the previous group's out-projection has to be done with R2 before it is overwritten
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < TF; ++t) {
+        const int f0 = 16 * (wave + 8 * t) + 4 * g;
+        if (f0 < NF) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(img + im.off_bqkv(grp) + (wave * TF + t) * 16 + 4 * g);
+#pragma unroll
+          for (int rt = 0; rt < TR; ++rt)
+            if (lds_ok[rt]) *reinterpret_cast<f32x4*>(&r2[prow[rt] * LQ + f0]) = acc[t][rt] + bv;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ================= (b) attention core per (news, head): a wave owns whole units; O overwrites Q in place
+    {
+      const int n_units = NPW * nh;
+      for (int u = wave; u < n_units; u += 8) {
+        const int nw = u / nh, hh = u - nw * nh;
+        float* Qb = r2 + (nw * S) * LQ + hh * dk;
+        const float* Kb = Qb + NW;
+        const float* Vb = Qb + 2 * NW;
+        int64_t news = news0 + nw;
+        if (news >= a.n_seq) news = a.n_seq - 1;
+        const int64_t msrc = a.ids ? (int64_t)a.ids[news] : news;
+        // K fragments: full 16-feature blocks as 16-byte reads (step j: feature 16 fb + 4 g + j), the d_k % 16
+        // tail one MFMA per 4 features (feature 16 nfull + 4 e + g)
+        f32x4 kf[2][nfull > 0 ? nfull : 1];
+        float kr[2][nrem > 0 ? nrem : 1];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          int key = 16 * kt + c;
+          if (key > S - 1) key = S - 1;
+          const float* kp = Kb + key * LQ;
+#pragma unroll
+          for (int fb = 0; fb < nfull; ++fb) kf[kt][fb] = *reinterpret_cast<const f32x4*>(kp + 16 * fb + 4 * g);
+#pragma unroll
+          for (int e = 0; e < nrem; ++e) kr[kt][e] = kp[16 * nfull + 4 * e + g];
+        }
+        // V^T fragments: vv[kt][dt][r] = V[key 16 kt + 4 g + r][16 dt + c]
+        float vv[2][ndt][4];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int dt = 0; dt < ndt; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              int key = 16 * kt + 4 * g + r;
+              if (key > S - 1) key = S - 1;  // its probability is exactly 0
+              const int dv = 16 * dt + c;
+              vv[kt][dt][r] = (dv < dk) ? Vb[key * LQ + dv] : 0.f;
+            }
+        for (int qt = 0; qt < KT; ++qt) {
+          const int query = 16 * qt + c;
+          const bool qok = query < S;
+          const int qc = qok ? query : S - 1;
+          const float* qp = Qb + qc * LQ;
+          f32x4 sc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+          for (int fb = 0; fb < nfull; ++fb) {
+            const f32x4 qf = *reinterpret_cast<const f32x4*>(qp + 16 * fb + 4 * g);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][fb][j], qf[j], sc[kt], 0, 0, 0);
+          }
+#pragma unroll
+          for (int e = 0; e < nrem; ++e) {
+            const float qr = qp[16 * nfull + 4 * e + g];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[kt][e], qr, sc[kt], 0, 0, 0);
+          }
+          // sc[kt][r] = S[query c][key 16 kt + 4 g + r]: scale, QUERY-row mask (layers.py:142-144), softmax over keys
+          const float mq = a.mask ? a.mask[msrc * S + qc] : 1.f;
+          float mx = -INFINITY;
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int key = 16 * kt + 4 * g + r;
+              float sv = sc[kt][r] * inv_sq;
+              if (mq == 0.f) sv = -1e9f;
+              if (key >= S) sv = -INFINITY;
+              sc[kt][r] = sv;
+              mx = fmaxf(mx, sv);
+            }
+          mx = fmaxf(mx, __shfl_xor(mx, 16));
+          mx = fmaxf(mx, __shfl_xor(mx, 32));
+          float sum = 0.f;
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float ev = attn_exp(sc[kt][r] - mx);
+              sc[kt][r] = ev;
+              sum += ev;
+            }
+          sum += __shfl_xor(sum, 16);
+          sum += __shfl_xor(sum, 32);
+          const float inv_sum = 1.f / sum;
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[kt][r] *= inv_sum;
+          // O^T[dv][query] = V^T P^T; 4 consecutive dv per lane -> one 16-byte store over this query's Q columns
+#pragma unroll
+          for (int dt = 0; dt < ndt; ++dt) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)  // S <= 16: the second key tile is all P = 0
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[kt][dt][r], sc[kt][r], o, 0, 0, 0);
+            const int dv0 = 16 * dt + 4 * g;
+            if (qok && dv0 < dk) *reinterpret_cast<f32x4*>(Qb + query * LQ + dv0) = o;
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ================= (c) out-projection, this group's columns of Wo: Y^T[d][row] += Wo[d][h0 d_k + k] O[row][k]
+    // wave (wf, wr): feature tiles wf + 4 t, the two row tiles of news wr
+    {
+      const float* wc = imgl + im.off_wo(grp) + (size_t)wf * TY * NF_FRAG;
+      const int nkc = (NW + 15) >> 4;
+      f32x4 fa[2][TY], fb[2][2];
+      auto load = [&](auto ST, int ks) {
+        constexpr int st = decltype(ST)::value;
+        const int k = ks * 16 + 4 * g;  // k < NW + 16 <= LQ; columns past NW meet zeros of the image
+        const float* wk = wc + (size_t)ks * (4 * TY * NF_FRAG);
+#pragma unroll
+        for (int t = 0; t < TY; ++t) fa[st][t] = *reinterpret_cast<const f32x4*>(wk + t * NF_FRAG);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fb[st][i] = *reinterpret_cast<const f32x4*>(&r2[prow_c[i] * LQ + k]);
+      };
+      auto mma = [&](auto ST) {
+        constexpr int st = decltype(ST)::value;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int t = 0; t < TY; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+              yacc[t][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[st][t][j], fb[st][i][j], yacc[t][i], 0, 0, 0);
+      };
+      NF_KLOOP(nkc)
+    }
+  }
+
+  // ================= Y = att output (+ bo) -> R1 [row][LY]  (X is dead: every group's projection has read it)
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < TY; ++t) {
+    const int d0 = 16 * (wf + 4 * t) + 4 * g;
+    if (d0 < D) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(img + im.off_bo() + (wf * TY + t) * 16 + 4 * g);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        if (ok_c[i]) *reinterpret_cast<f32x4*>(&r1[prow_c[i] * LY + d0]) = yacc[t][i] + bv;
+    }
+  }
+  __syncthreads();
+
+  // ================= fc1 + tanh + fc2: e[row] = sum_a w2[a] tanh(W1[a] . Y[row] + b1[a])   (layers.py:60)
+  {
+    const float* w1i = imgl + im.off_w1() + (size_t)wave * TA * NF_FRAG;
+    f32x4 acc[TA][TR];
+#pragma unroll
+    for (int t = 0; t < TA; ++t)
+#pragma unroll
+      for (int rt = 0; rt < TR; ++rt) acc[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 fa[2][TA], fb[2][TR];
+    auto load = [&](auto ST, int ks) {
+      constexpr int st = decltype(ST)::value;
+      int kc = ks * 16 + 4 * g;
+      if (kc > D - 4) kc = D - 4;
+      const float* wk = w1i + (size_t)ks * (8 * TA * NF_FRAG);
+#pragma unroll
+      for (int t = 0; t < TA; ++t) fa[st][t] = *reinterpret_cast<const f32x4*>(wk + t * NF_FRAG);
+#pragma unroll
+      for (int rt = 0; rt < TR; ++rt) fb[st][rt] = *reinterpret_cast<const f32x4*>(&r1[prow[rt] * LY + kc]);
+    };
+    auto mma = [&](auto ST) {
+      constexpr int st = decltype(ST)::value;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < TA; ++t)
+#pragma unroll
+          for (int rt = 0; rt < TR; ++rt)
+            acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[st][t][j], fb[st][rt][j], acc[t][rt], 0, 0, 0);
+    };
+    NF_KLOOP(nk)
+    float e[TR];
+#pragma unroll
+    for (int rt = 0; rt < TR; ++rt) e[rt] = 0.f;
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {
+      // b1 / w2 images are zero past A: a padded hidden unit contributes w2 * tanh(0 + 0) = 0
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(img + im.off_b1() + (wave * TA + t) * 16 + 4 * g);
+      const f32x4 w2 = *reinterpret_cast<const f32x4*>(img + im.off_w2() + (wave * TA + t) * 16 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int rt = 0; rt < TR; ++rt) e[rt] = fmaf(w2[r], tanhf(acc[t][rt][r] + b1[r]), e[rt]);
+    }
+#pragma unroll
+    for (int rt = 0; rt < TR; ++rt) {
+      float v = e[rt];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (g == 0) epart[wave * (NPW * 32) + 16 * rt + c] = v;
+    }
+  }
+  __syncthreads();
+
+  // ================= a = exp(e + b2) * m  (un-stabilised, layers.py:61-62), normalise (+1e-8), weighted sum of Y
+  if (tid < NPW * 32) {
+    const int nw = tid >> 5, sp = tid & 31;
+    int64_t news = news0 + nw;
+    if (news >= a.n_seq) news = a.n_seq - 1;
+    const int64_t msrc = a.ids ? (int64_t)a.ids[news] : news;
+    float v = 0.f;
+    if (sp < S) {
+      float ev = a.b2 ? a.b2[0] : 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) ev += epart[w * (NPW * 32) + tid];
+      v = expf(ev);
+      if (a.mask) v *= a.mask[msrc * S + sp];
+    }
+    aw[tid] = v;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < NPW * D; idx += NF_THREADS) {
+    const int nw = idx / D, d = idx - nw * D;
+    const int64_t news = news0 + nw;
+    float den = 0.f;
+    for (int s = 0; s < S; ++s) den += aw[nw * 32 + s];
+    den += 1e-8f;
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc = fmaf(aw[nw * 32 + s] / den, r1[(nw * S + s) * LY + d], acc);
+    if (news < a.n_seq) a.p[news * a.ldp + d] = acc;
+  }
+  if (a.hm && tid < NPW) {
+    const int64_t news = news0 + tid;
+    if (news < a.n_seq) {
+      const int64_t msrc = a.ids ? (int64_t)a.ids[news] : news;
+      float ms = 0.f;
+      for (int s = 0; s < S; ++s) ms += a.mask ? a.mask[msrc * S + s] : 1.f;
+      a.hm[news] = fminf(fmaxf(ms, 0.f), 1.f);
+    }
+  }
+}
+
+int stride8(int n) {  // smallest stride >= n with stride % 16 == 8: conflict-free 16-byte fragment reads (16 rows x 4 chunks)
+  int s = (n + 15) / 16 * 16 + 8;
+  if (s - 16 >= n) s -= 16;
+  return s;
+}
+
+}  // namespace
+
+bool news_fused_plan(int S, int D, int n_heads, int A, NewsFusedPlan* plan) {
+  if (S <= 0 || S > 32 || D < 4 || D % 4 != 0 || D > 16 * 4 * NF_TY || n_heads <= 0 || D % n_heads != 0) return false;
+  const int dk = D / n_heads;
+  if (dk % 4 != 0 || dk > 32 || A <= 0 || A > 16 * 8 * NF_TA) return false;
+  int hg = (16 * 8 * NF_TF) / (3 * dk);
+  if (hg > n_heads) hg = n_heads;
+  if (hg < 1) return false;
+  const int lq = stride8(3 * hg * dk), ly = stride8(D);
+  const size_t floats = (size_t)NF_NPW * S * (lq + ly) + 8 * NF_NPW * 32 + NF_NPW * 32;
+  if (floats * 4 > 160 * 1024) return false;
+  if (plan) {
+    plan->npw = NF_NPW;
+    plan->hg = hg;
+    plan->lq = lq;
+    plan->ly = ly;
+    plan->lds_bytes = floats * 4;
+    plan->n_groups = (n_heads + hg - 1) / hg;
+    plan->nk = (D + 15) / 16;
+    plan->nkc = (hg * dk + 15) / 16;
+    plan->img_bytes = NfImg{plan->n_groups, plan->nk, plan->nkc}.total() * sizeof(float);
+  }
+  return true;
+}
+
+// upper bound of NewsFusedPlan::img_bytes over every head count (workspace queries do not know n_heads): a full head
+// group covers at least 192 of the 256 Q|K|V columns a pass can hold, so there are at most ceil(3D / 192) + 1 groups
+size_t news_fused_img_bound_bytes(int S, int D, int A) {
+  if (S <= 0 || S > 32 || D < 4 || D % 4 != 0 || D > 16 * 4 * NF_TY || A <= 0 || A > 16 * 8 * NF_TA) return 0;
+  const int ng = (3 * D + 191) / 192 + 1;
+  return NfImg{ng, (D + 15) / 16, 16}.total() * sizeof(float);
+}
+
+hipError_t launch_news_fused(const NewsFusedArgs& a, hipStream_t stream) {
+  if (a.n_seq <= 0) return hipSuccess;
+  NewsFusedPlan p;
+  if (!news_fused_plan(a.S, a.D, a.n_heads, a.A, &p) || a.d_k * a.n_heads != a.D) return hipErrorInvalidValue;
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (!al16(a.x) || !al16(a.wq) || !al16(a.wk) || !al16(a.wv) || !al16(a.wo) || !al16(a.w1) || !a.img || !al16(a.img))
+    return hipErrorInvalidValue;
+  // prologue: the weights in MFMA fragment order (see the file header); ~2 MB, rebuilt per call -- the ABI keeps no state
+  const NfImg im{p.n_groups, p.nk, p.nkc};
+  const size_t n4 = im.total() / 4;
+  hipLaunchKernelGGL(news_fused_prep_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, a, im, p.hg, a.img);
+  hipError_t pe = hipGetLastError();
+  if (pe != hipSuccess) return pe;
+  const int64_t grid = (a.n_seq + p.npw - 1) / p.npw;
+  if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  // one instantiation per head width (d_k / 4 = 1 .. 8); each needs its dynamic-LDS limit raised once
+  static std::once_flag once[8];
+  static hipError_t attr_rc[8];
+  hipError_t rc = hipErrorInvalidValue;
+#define NF_CASE(Q)                                                                                                   \
+  case Q:                                                                                                            \
+    std::call_once(once[Q - 1], [] {                                                                                 \
+      attr_rc[Q - 1] = hipFuncSetAttribute(reinterpret_cast<const void*>(&news_fused_kernel<Q>),                     \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
+    });                                                                                                              \
+    if (attr_rc[Q - 1] != hipSuccess) return attr_rc[Q - 1];                                                         \
+    hipLaunchKernelGGL((news_fused_kernel<Q>), dim3((unsigned)grid), dim3(NF_THREADS), p.lds_bytes, stream, a, im, a.img, \
+                       p.hg, p.lq, p.ly);                                                                            \
+    rc = hipGetLastError();                                                                                          \
+    break;
+  switch (a.d_k / 4) {
+    NF_CASE(1) NF_CASE(2) NF_CASE(3) NF_CASE(4) NF_CASE(5) NF_CASE(6) NF_CASE(7) NF_CASE(8)
+    default: break;
+  }
+#undef NF_CASE
+  return rc;
+}
+
+}  // namespace xnrs

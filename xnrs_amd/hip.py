@@ -24,7 +24,7 @@ SYMBOLS = (
     "xnrs_additive_workspace_bytes", "xnrs_additive_attention_fwd", "xnrs_masked_mean_fwd", "xnrs_collapse_mask",
     "xnrs_text_encoder_workspace_bytes", "xnrs_text_encoder_fwd", "xnrs_user_encoder_workspace_bytes",
     "xnrs_user_encoder_fwd", "xnrs_dot_scoring_fwd", "xnrs_profile_enable", "xnrs_profile_read",
-    "xnrs_set_gemm_mode", "xnrs_get_gemm_mode",
+    "xnrs_set_gemm_mode", "xnrs_get_gemm_mode", "xnrs_reload_knobs",
     "xnrs_text_encoder_unpadded_workspace_bytes", "xnrs_text_encoder_fwd_unpadded",
     "xnrs_seq_encoder_saved_bytes", "xnrs_seq_encoder_fwd_train", "xnrs_seq_encoder_bwd_workspace_bytes",
     "xnrs_seq_encoder_bwd", "xnrs_seq_encoder_bwd_live", "xnrs_linear_bwd_workspace_bytes", "xnrs_linear_bwd",
@@ -33,7 +33,7 @@ SYMBOLS = (
     "xnrs_infonce_saved_bytes", "xnrs_infonce_fwd", "xnrs_infonce_bwd",
 )
 POOL_NONE = -1
-PROFILE_STAGES = ("qkv_gemm", "attention_core", "out_gemm", "fc1_tanh_gemm", "pool", "head_gemms")
+PROFILE_STAGES = ("qkv_gemm", "attention_core", "out_gemm", "fc1_tanh_gemm", "pool", "head_gemms", "news_fused")
 
 
 class XnrsHipError(RuntimeError):
@@ -157,6 +157,8 @@ def lib():
     l.xnrs_set_gemm_mode.argtypes = [i32]
     l.xnrs_get_gemm_mode.restype = i32
     l.xnrs_get_gemm_mode.argtypes = []
+    l.xnrs_reload_knobs.restype = i32
+    l.xnrs_reload_knobs.argtypes = []
     l.xnrs_profile_enable.restype = i32
     l.xnrs_profile_enable.argtypes = [C.c_uint32]
     l.xnrs_profile_read.restype = i32
@@ -187,6 +189,39 @@ def set_gemm_mode(mode: int) -> int:
 
 def get_gemm_mode() -> int:
     return lib().xnrs_get_gemm_mode()
+
+
+class knobs:
+    """Development knobs for A/B runs and tests: ``with hip.knobs(XNRS_GEMM_PIPE="1"): ...`` sets the environment
+    variables, makes the library re-read them (it reads them only at load and on xnrs_reload_knobs), and restores
+    both on exit.  A value of None removes the variable."""
+
+    def __init__(self, **env):
+        self.env = env
+        self.old = {}
+
+    def __enter__(self):
+        for k, v in self.env.items():
+            self.old[k] = os.environ.get(k)
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+        lib().xnrs_reload_knobs()
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        lib().xnrs_reload_knobs()
+        return False
+
+
+def reload_knobs():
+    lib().xnrs_reload_knobs()
 
 
 def profile_enable(stage_mask: int):
