@@ -25,6 +25,7 @@ SHAPES = [
     (30, 320, 16, 256, 33), (30, 300, 15, 256, 17), (32, 320, 16, 64, 8), (17, 320, 16, 256, 5), (16, 300, 15, 32, 4),
     (1, 32, 4, 16, 3), (5, 16, 4, 16, 7), (8, 32, 4, 16, 6), (20, 48, 4, 16, 9), (30, 64, 4, 32, 11), (25, 96, 4, 32, 2),
     (31, 224, 8, 64, 5), (9, 128, 4, 32, 1), (30, 256, 16, 256, 21), (12, 320, 10, 64, 3), (30, 240, 12, 48, 10),
+    (8, 32, 4, 10, 5),
 ]
 
 
@@ -56,6 +57,7 @@ def test_fused_equals_oracle_and_unfused(shape):
     with torch.no_grad():
         (y, hm), used = stages_used(lambda: enc((xd, md)))
         assert "news_fused" in used and not (used & {"qkv_gemm", "attention_core", "out_gemm", "fc1_tanh_gemm", "pool"}), used
+        assert "head_gemms" in used  # the MLP head stays a GEMM pair over all news
         with hip.knobs(XNRS_NEWS_FUSED="0"):
             (y0, hm0), used0 = stages_used(lambda: enc((xd, md)))
         assert "news_fused" not in used0 and "qkv_gemm" in used0

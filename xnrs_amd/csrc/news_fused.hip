@@ -146,17 +146,70 @@ __global__ __launch_bounds__(256) void news_fused_prep_kernel(NewsFusedArgs a, N
   *reinterpret_cast<f32x4*>(img + e) = v;
 }
 
-// k loop of the three big products: two fragment register sets, the loads of step ks+1 are issued before the MFMAs
-// of step ks
-#define NF_KLOOP(NK)                                 \
-  load(IC<0>{}, 0);                                  \
-  for (int ks = 0; ks < (NK); ks += 2) {             \
-    if (ks + 1 < (NK)) load(IC<1>{}, ks + 1);        \
-    mma(IC<0>{});                                    \
-    if (ks + 1 < (NK)) {                             \
-      if (ks + 2 < (NK)) load(IC<0>{}, ks + 2);      \
-      mma(IC<1>{});                                  \
-    }                                                \
+// Diagnostic build only (make stamps; tools/nf_stamps.py): per-wave s_memtime stamps at the phase boundaries, written
+// to a buffer nothing else reads.  The shipped library contains none of this.
+#ifdef XNRS_NF_STAMPS
+__device__ unsigned long long* g_nf_stamps_dev = nullptr;
+#define g_nf_stamps g_nf_stamps_dev
+constexpr int NF_NSTAMP = 32;
+#define NF_STAMP(I)                                                                                             \
+  do {                                                                                                          \
+    if (g_nf_stamps && lane == 0 && blockIdx.x < 1024)                                                          \
+      g_nf_stamps[((size_t)blockIdx.x * 8 + wave) * NF_NSTAMP + (I)] = __builtin_amdgcn_s_memtime();            \
+  } while (0)
+#else
+#define NF_STAMP(I)
+#endif
+
+// k loop of the three big products.  Two fragment register sets: the fragments of step ks+1 are loaded WHILE the
+// MFMAs of step ks issue.  Three things hipcc does not do by itself, each measured (tools/nf_stamps.py):
+//   * the loop body is straight-line code -- every load unconditional, the last one re-reads step NK-1 -- so the
+//     vmcnt / lgkmcnt waits are exact counts (with the prefetch inside `if (ks + 1 < NK)` it waited vmcnt(0) at the
+//     join, i.e. for the prefetch it had just issued);
+//   * sched_barriers pin the order (left alone the scheduler sinks the loads ~20 MFMAs into the burst);
+//   * the loads are SPREAD over the burst, one group behind each quarter of the MFMAs (step j of the four k of a
+//     fragment): the two waves of a SIMD run in lockstep (fair MFMA arbitration), so a cluster of ~25 non-MFMA
+//     instructions at the top of the body left the matrix pipe idle ~10 % of every step in BOTH of them.
+#define NF_SB __builtin_amdgcn_sched_barrier(0)
+#define NF_HALF(CUR, NXT, KSN) \
+  mma(CUR, IC<0>{});           \
+  NF_SB;                       \
+  load_w(NXT, KSN);            \
+  NF_SB;                       \
+  mma(CUR, IC<1>{});           \
+  NF_SB;                       \
+  load_b(NXT, KSN, IC<0>{});   \
+  NF_SB;                       \
+  mma(CUR, IC<2>{});           \
+  NF_SB;                       \
+  load_b(NXT, KSN, IC<1>{});   \
+  NF_SB;                       \
+  mma(CUR, IC<3>{});           \
+  NF_SB;
+// MFMA arbitration between the two waves of a SIMD goes to the OLDER wave: left alone, waves 0-3 finished a 41 k-cycle
+// projection loop 6 k cycles before waves 4-7, which then ran the tail alone (exposed waits) while waves 0-3 sat in the
+// barrier.  Alternating a raised priority between the two halves every k step keeps them level.
+#define NF_PRIO(FIRST)                                             \
+  if ((wave >= 4) == (FIRST)) __builtin_amdgcn_s_setprio(1);       \
+  else __builtin_amdgcn_s_setprio(0);
+#define NF_KLOOP(NK)                                                \
+  load_w(IC<0>{}, 0);                                               \
+  load_b(IC<0>{}, 0, IC<0>{});                                      \
+  load_b(IC<0>{}, 0, IC<1>{});                                      \
+  NF_SB;                                                            \
+  for (int ks = 0; ks + 1 < (NK); ks += 2) {                        \
+    NF_PRIO(true)                                                   \
+    NF_HALF(IC<0>{}, IC<1>{}, ks + 1)                               \
+    const int ksn = ks + 2 < (NK) ? ks + 2 : (NK)-1;                \
+    NF_PRIO(false)                                                  \
+    NF_HALF(IC<1>{}, IC<0>{}, ksn)                                  \
+  }                                                                 \
+  __builtin_amdgcn_s_setprio(0);                                    \
+  if ((NK)&1) {                                                     \
+    mma(IC<0>{}, IC<0>{});                                          \
+    mma(IC<0>{}, IC<1>{});                                          \
+    mma(IC<0>{}, IC<2>{});                                          \
+    mma(IC<0>{}, IC<3>{});                                          \
   }
 
 template <int DK4>
@@ -170,7 +223,7 @@ __global__ __launch_bounds__(NF_THREADS, 2) void news_fused_kernel(NewsFusedArgs
   float* r1 = smem;                      // X, later Y: [nrow][LY]
   float* r2 = r1 + nrow * LY;            // Q|K|V of a head group: [nrow][LQ]
   float* epart = r2 + nrow * LQ;         // [8 waves][NPW * 32] partial fc2 scores
-  float* aw = epart + 8 * NPW * 32;      // [NPW * 32] un-normalised pooling weights
+  float* aw = epart + 8 * NPW * 32;      // [2][NPW * 32] pooling weights: exp(e) m, then normalised
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -223,9 +276,10 @@ __global__ __launch_bounds__(NF_THREADS, 2) void news_fused_kernel(NewsFusedArgs
   const int nk = im.nk;
   const float* imgl = img + lane * 4;  // this lane's 16 bytes of every weight fragment
   const float inv_sq = a.scaled ? 1.f / sqrtf((float)dk) : 1.f;
-  const int KT = (S + 15) >> 4;
   constexpr int nfull = dk >> 4, nrem = (dk & 15) >> 2, ndt = (dk + 15) >> 4;
+  NF_STAMP(0);
   __syncthreads();  // X is in R1
+  NF_STAMP(1);
 
   const int n_groups = im.n_groups;
   for (int grp = 0; grp < n_groups; ++grp) {
@@ -246,29 +300,32 @@ __global__ __launch_bounds__(NF_THREADS, 2) void news_fused_kernel(NewsFusedArgs
 #pragma unroll
         for (int rt = 0; rt < TR; ++rt) acc[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
       f32x4 fa[2][TF], fb[2][TR];
-      auto load = [&](auto ST, int ks) {
+      auto load_w = [&](auto ST, int ks) {
         constexpr int st = decltype(ST)::value;
-        int kc = ks * 16 + 4 * g;
-        if (kc > D - 4) kc = D - 4;  // k tail: the weight image is zero there, the read only has to stay inside the row
         const float* wk = wa + (size_t)ks * (8 * TF * NF_FRAG);
 #pragma unroll
         for (int t = 0; t < TF; ++t) fa[st][t] = *reinterpret_cast<const f32x4*>(wk + t * NF_FRAG);
-#pragma unroll
-        for (int rt = 0; rt < TR; ++rt) fb[st][rt] = *reinterpret_cast<const f32x4*>(&r1[prow[rt] * LY + kc]);
       };
-      auto mma = [&](auto ST) {
-        constexpr int st = decltype(ST)::value;
+      auto load_b = [&](auto ST, int ks, auto HALF) {  // the row tiles of news HALF
+        constexpr int st = decltype(ST)::value, h = decltype(HALF)::value;
+        int kc = ks * 16 + 4 * g;
+        if (kc > D - 4) kc = D - 4;  // k tail: the weight image is zero there, the read only has to stay inside the row
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int rt = 2 * h; rt < 2 * h + 2; ++rt) fb[st][rt] = *reinterpret_cast<const f32x4*>(&r1[prow[rt] * LY + kc]);
+      };
+      auto mma = [&](auto ST, auto J) {
+        constexpr int st = decltype(ST)::value, j = decltype(J)::value;
 #pragma unroll
-          for (int t = 0; t < TF; ++t)
+        for (int t = 0; t < TF; ++t)
 #pragma unroll
-            for (int rt = 0; rt < TR; ++rt)
-              acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[st][t][j], fb[st][rt][j], acc[t][rt], 0, 0, 0);
+          for (int rt = 0; rt < TR; ++rt)
+            acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[st][t][j], fb[st][rt][j], acc[t][rt], 0, 0, 0);
       };
       NF_KLOOP(nk)
+      NF_STAMP(2 + 6 * (grp & 3));
       // the previous group's out-projection has to be done with R2 before it is overwritten
       __syncthreads();
+      NF_STAMP(3 + 6 * (grp & 3));
 #pragma unroll
       for (int t = 0; t < TF; ++t) {
         const int f0 = 16 * (wave + 8 * t) + 4 * g;
@@ -281,6 +338,7 @@ __global__ __launch_bounds__(NF_THREADS, 2) void news_fused_kernel(NewsFusedArgs
       }
     }
     __syncthreads();
+    NF_STAMP(4 + 6 * (grp & 3));
 
     // ================= (b) attention core per (news, head): a wave owns whole units; O overwrites Q in place
     {
@@ -320,38 +378,47 @@ __global__ __launch_bounds__(NF_THREADS, 2) void news_fused_kernel(NewsFusedArgs
               const int dv = 16 * dt + c;
               vv[kt][dt][r] = (dv < dk) ? Vb[key * LQ + dv] : 0.f;
             }
-        for (int qt = 0; qt < KT; ++qt) {
+        // both 16-query tiles in one straight run (the two softmax chains interleave); for S <= 16 the second tile
+        // is a clamped duplicate whose stores are predicated off
+        f32x4 sc[2][2];
+        int qrow[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
           const int query = 16 * qt + c;
-          const bool qok = query < S;
-          const int qc = qok ? query : S - 1;
-          const float* qp = Qb + qc * LQ;
-          f32x4 sc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+          qrow[qt] = query < S ? query : S - 1;
+          const float* qp = Qb + qrow[qt] * LQ;
+          sc[qt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+          sc[qt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int fb = 0; fb < nfull; ++fb) {
             const f32x4 qf = *reinterpret_cast<const f32x4*>(qp + 16 * fb + 4 * g);
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-              for (int j = 0; j < 4; ++j) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][fb][j], qf[j], sc[kt], 0, 0, 0);
+              for (int j = 0; j < 4; ++j)
+                sc[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][fb][j], qf[j], sc[qt][kt], 0, 0, 0);
           }
 #pragma unroll
           for (int e = 0; e < nrem; ++e) {
             const float qr = qp[16 * nfull + 4 * e + g];
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[kt][e], qr, sc[kt], 0, 0, 0);
+            for (int kt = 0; kt < 2; ++kt) sc[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[kt][e], qr, sc[qt][kt], 0, 0, 0);
           }
-          // sc[kt][r] = S[query c][key 16 kt + 4 g + r]: scale, QUERY-row mask (layers.py:142-144), softmax over keys
-          const float mq = a.mask ? a.mask[msrc * S + qc] : 1.f;
+        }
+        // sc[qt][kt][r] = S[query 16 qt + c][key 16 kt + 4 g + r]: scale, QUERY-row mask (layers.py:142-144), softmax
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          const float mq = a.mask ? a.mask[msrc * S + qrow[qt]] : 1.f;
           float mx = -INFINITY;
 #pragma unroll
           for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int key = 16 * kt + 4 * g + r;
-              float sv = sc[kt][r] * inv_sq;
+              float sv = sc[qt][kt][r] * inv_sq;
               if (mq == 0.f) sv = -1e9f;
               if (key >= S) sv = -INFINITY;
-              sc[kt][r] = sv;
+              sc[qt][kt][r] = sv;
               mx = fmaxf(mx, sv);
             }
           mx = fmaxf(mx, __shfl_xor(mx, 16));
@@ -361,8 +428,8 @@ __global__ __launch_bounds__(NF_THREADS, 2) void news_fused_kernel(NewsFusedArgs
           for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float ev = attn_exp(sc[kt][r] - mx);
-              sc[kt][r] = ev;
+              const float ev = attn_exp(sc[qt][kt][r] - mx);
+              sc[qt][kt][r] = ev;
               sum += ev;
             }
           sum += __shfl_xor(sum, 16);
@@ -371,22 +438,26 @@ __global__ __launch_bounds__(NF_THREADS, 2) void news_fused_kernel(NewsFusedArgs
 #pragma unroll
           for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sc[kt][r] *= inv_sum;
-          // O^T[dv][query] = V^T P^T; 4 consecutive dv per lane -> one 16-byte store over this query's Q columns
+            for (int r = 0; r < 4; ++r) sc[qt][kt][r] *= inv_sum;
+        }
+        // O^T[dv][query] = V^T P^T; 4 consecutive dv per lane -> one 16-byte store over this query's Q columns
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
           for (int dt = 0; dt < ndt; ++dt) {
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)  // S <= 16: the second key tile is all P = 0
 #pragma unroll
-              for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[kt][dt][r], sc[kt][r], o, 0, 0, 0);
-            const int dv0 = 16 * dt + 4 * g;
-            if (qok && dv0 < dk) *reinterpret_cast<f32x4*>(Qb + query * LQ + dv0) = o;
+              for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[kt][dt][r], sc[qt][kt][r], o, 0, 0, 0);
+            const int query = 16 * qt + c, dv0 = 16 * dt + 4 * g;
+            if (query < S && dv0 < dk) *reinterpret_cast<f32x4*>(Qb + query * LQ + dv0) = o;
           }
-        }
       }
     }
+    NF_STAMP(5 + 6 * (grp & 3));
     __syncthreads();
+    NF_STAMP(6 + 6 * (grp & 3));
 
     // ================= (c) out-projection, this group's columns of Wo: Y^T[d][row] += Wo[d][h0 d_k + k] O[row][k]
     // wave (wf, wr): feature tiles wf + 4 t, the two row tiles of news wr
@@ -394,31 +465,33 @@ __global__ __launch_bounds__(NF_THREADS, 2) void news_fused_kernel(NewsFusedArgs
       const float* wc = imgl + im.off_wo(grp) + (size_t)wf * TY * NF_FRAG;
       const int nkc = (NW + 15) >> 4;
       f32x4 fa[2][TY], fb[2][2];
-      auto load = [&](auto ST, int ks) {
+      auto load_w = [&](auto ST, int ks) {
         constexpr int st = decltype(ST)::value;
-        const int k = ks * 16 + 4 * g;  // k < NW + 16 <= LQ; columns past NW meet zeros of the image
         const float* wk = wc + (size_t)ks * (4 * TY * NF_FRAG);
 #pragma unroll
         for (int t = 0; t < TY; ++t) fa[st][t] = *reinterpret_cast<const f32x4*>(wk + t * NF_FRAG);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) fb[st][i] = *reinterpret_cast<const f32x4*>(&r2[prow_c[i] * LQ + k]);
       };
-      auto mma = [&](auto ST) {
-        constexpr int st = decltype(ST)::value;
+      auto load_b = [&](auto ST, int ks, auto HALF) {
+        constexpr int st = decltype(ST)::value, h = decltype(HALF)::value;
+        const int k = ks * 16 + 4 * g;  // k < NW + 16 <= LQ; columns past NW meet zeros of the image
+        fb[st][h] = *reinterpret_cast<const f32x4*>(&r2[prow_c[h] * LQ + k]);
+      };
+      auto mma = [&](auto ST, auto J) {
+        constexpr int st = decltype(ST)::value, j = decltype(J)::value;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int t = 0; t < TY; ++t)
 #pragma unroll
-          for (int t = 0; t < TY; ++t)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-              yacc[t][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[st][t][j], fb[st][i][j], yacc[t][i], 0, 0, 0);
+          for (int i = 0; i < 2; ++i)
+            yacc[t][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[st][t][j], fb[st][i][j], yacc[t][i], 0, 0, 0);
       };
       NF_KLOOP(nkc)
+      NF_STAMP(7 + 6 * (grp & 3));
     }
   }
 
   // ================= Y = att output (+ bo) -> R1 [row][LY]  (X is dead: every group's projection has read it)
   __syncthreads();
+  NF_STAMP(26);
 #pragma unroll
   for (int t = 0; t < TY; ++t) {
     const int d0 = 16 * (wf + 4 * t) + 4 * g;
@@ -430,6 +503,7 @@ __global__ __launch_bounds__(NF_THREADS, 2) void news_fused_kernel(NewsFusedArgs
     }
   }
   __syncthreads();
+  NF_STAMP(27);
 
   // ================= fc1 + tanh + fc2: e[row] = sum_a w2[a] tanh(W1[a] . Y[row] + b1[a])   (layers.py:60)
   {
@@ -440,27 +514,29 @@ __global__ __launch_bounds__(NF_THREADS, 2) void news_fused_kernel(NewsFusedArgs
 #pragma unroll
       for (int rt = 0; rt < TR; ++rt) acc[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 fa[2][TA], fb[2][TR];
-    auto load = [&](auto ST, int ks) {
+    auto load_w = [&](auto ST, int ks) {
       constexpr int st = decltype(ST)::value;
-      int kc = ks * 16 + 4 * g;
-      if (kc > D - 4) kc = D - 4;
       const float* wk = w1i + (size_t)ks * (8 * TA * NF_FRAG);
 #pragma unroll
       for (int t = 0; t < TA; ++t) fa[st][t] = *reinterpret_cast<const f32x4*>(wk + t * NF_FRAG);
-#pragma unroll
-      for (int rt = 0; rt < TR; ++rt) fb[st][rt] = *reinterpret_cast<const f32x4*>(&r1[prow[rt] * LY + kc]);
     };
-    auto mma = [&](auto ST) {
-      constexpr int st = decltype(ST)::value;
+    auto load_b = [&](auto ST, int ks, auto HALF) {
+      constexpr int st = decltype(ST)::value, h = decltype(HALF)::value;
+      int kc = ks * 16 + 4 * g;
+      if (kc > D - 4) kc = D - 4;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int rt = 2 * h; rt < 2 * h + 2; ++rt) fb[st][rt] = *reinterpret_cast<const f32x4*>(&r1[prow[rt] * LY + kc]);
+    };
+    auto mma = [&](auto ST, auto J) {
+      constexpr int st = decltype(ST)::value, j = decltype(J)::value;
 #pragma unroll
-        for (int t = 0; t < TA; ++t)
+      for (int t = 0; t < TA; ++t)
 #pragma unroll
-          for (int rt = 0; rt < TR; ++rt)
-            acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[st][t][j], fb[st][rt][j], acc[t][rt], 0, 0, 0);
+        for (int rt = 0; rt < TR; ++rt)
+          acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[st][t][j], fb[st][rt][j], acc[t][rt], 0, 0, 0);
     };
     NF_KLOOP(nk)
+    NF_STAMP(28);
     float e[TR];
 #pragma unroll
     for (int rt = 0; rt < TR; ++rt) e[rt] = 0.f;
@@ -482,7 +558,9 @@ __global__ __launch_bounds__(NF_THREADS, 2) void news_fused_kernel(NewsFusedArgs
       if (g == 0) epart[wave * (NPW * 32) + 16 * rt + c] = v;
     }
   }
+  NF_STAMP(29);
   __syncthreads();
+  NF_STAMP(30);
 
   // ================= a = exp(e + b2) * m  (un-stabilised, layers.py:61-62), normalise (+1e-8), weighted sum of Y
   if (tid < NPW * 32) {
@@ -501,16 +579,30 @@ __global__ __launch_bounds__(NF_THREADS, 2) void news_fused_kernel(NewsFusedArgs
     aw[tid] = v;
   }
   __syncthreads();
-  for (int idx = tid; idx < NPW * D; idx += NF_THREADS) {
-    const int nw = idx / D, d = idx - nw * D;
-    const int64_t news = news0 + nw;
+  if (tid < NPW * 32) {  // a / (sum_s a + 1e-8), layers.py:63
+    const int nw = tid >> 5;
     float den = 0.f;
     for (int s = 0; s < S; ++s) den += aw[nw * 32 + s];
-    den += 1e-8f;
-    float acc = 0.f;
-    for (int s = 0; s < S; ++s) acc = fmaf(aw[nw * 32 + s] / den, r1[(nw * S + s) * LY + d], acc);
-    if (news < a.n_seq) a.p[news * a.ldp + d] = acc;
+    aw[NPW * 32 + tid] = aw[tid] / (den + 1e-8f);
   }
+  __syncthreads();
+  const int d4n = D >> 2;
+  for (int idx = tid; idx < NPW * d4n; idx += NF_THREADS) {  // one 16-byte column chunk of one news per thread
+    const int nw = idx / d4n, d4 = idx - nw * d4n;
+    const int64_t news = news0 + nw;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) {
+      const float w = aw[NPW * 32 + nw * 32 + s];
+      const f32x4 yv = *reinterpret_cast<const f32x4*>(&r1[(nw * S + s) * LY + 4 * d4]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = fmaf(w, yv[r], acc[r]);
+    }
+    if (news < a.n_seq) *reinterpret_cast<f32x4*>(a.p + news * a.ldp + 4 * d4) = acc;
+  }
+  // (The MLP head stays a GEMM pair over ALL news after this kernel.  Running it here -- one thread per output
+  // feature, both news per weight chunk -- was measured: every workgroup then streams the head's 590 KB of weights
+  // for 2 news, 10 microseconds per round at L2 -> CU bandwidth, no better than the two launches at 1024 news and far
+  // worse at 28 000.)
   if (a.hm && tid < NPW) {
     const int64_t news = news0 + tid;
     if (news < a.n_seq) {
@@ -520,6 +612,7 @@ __global__ __launch_bounds__(NF_THREADS, 2) void news_fused_kernel(NewsFusedArgs
       a.hm[news] = fminf(fmaxf(ms, 0.f), 1.f);
     }
   }
+  NF_STAMP(31);
 }
 
 int stride8(int n) {  // smallest stride >= n with stride % 16 == 8: conflict-free 16-byte fragment reads (16 rows x 4 chunks)
@@ -538,7 +631,7 @@ bool news_fused_plan(int S, int D, int n_heads, int A, NewsFusedPlan* plan) {
   if (hg > n_heads) hg = n_heads;
   if (hg < 1) return false;
   const int lq = stride8(3 * hg * dk), ly = stride8(D);
-  const size_t floats = (size_t)NF_NPW * S * (lq + ly) + 8 * NF_NPW * 32 + NF_NPW * 32;
+  const size_t floats = (size_t)NF_NPW * S * (lq + ly) + 8 * NF_NPW * 32 + 2 * NF_NPW * 32;
   if (floats * 4 > 160 * 1024) return false;
   if (plan) {
     plan->npw = NF_NPW;
@@ -601,3 +694,9 @@ hipError_t launch_news_fused(const NewsFusedArgs& a, hipStream_t stream) {
 }
 
 }  // namespace xnrs
+
+#ifdef XNRS_NF_STAMPS
+extern "C" int xnrs_debug_nf_set_stamps(unsigned long long* dev_buf) {  // diagnostic build only
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(xnrs::g_nf_stamps_dev), &dev_buf, sizeof(dev_buf));
+}
+#endif
