@@ -55,7 +55,8 @@ def test_fused_equals_oracle_and_unfused(shape):
     x, m = synth.token_block(rng, 1, n, S, D, min_len=1, full_pad_prob=0.2)
     xd, md = x.to(DEV), m.to(DEV)
     with torch.no_grad():
-        (y, hm), used = stages_used(lambda: enc((xd, md)))
+        with hip.knobs(XNRS_NEWS_FUSED="2"):  # "2": whenever eligible (the default dispatch wants >= 26 tokens, >= 384 news)
+            (y, hm), used = stages_used(lambda: enc((xd, md)))
         assert "news_fused" in used and not (used & {"qkv_gemm", "attention_core", "out_gemm", "fc1_tanh_gemm", "pool"}), used
         assert "head_gemms" in used  # the MLP head stays a GEMM pair over all news
         with hip.knobs(XNRS_NEWS_FUSED="0"):
@@ -74,7 +75,7 @@ def test_fused_with_id_gather_is_bitwise_the_materialised_gather():
     tx, tm = synth.token_block(rng, 1, 40, S, D, min_len=3)
     tx, tm = tx.reshape(40, S, D).to(DEV), tm.reshape(40, S).to(DEV)
     ids = torch.from_numpy(rng.integers(0, 40, size=(3, 9)).astype(np.int32)).to(DEV)
-    with torch.no_grad():
+    with torch.no_grad(), hip.knobs(XNRS_NEWS_FUSED="2"):
         (y, hm), used = stages_used(lambda: enc.forward_ids(tx, tm, ids))
         assert "news_fused" in used
         g = ids.long()
@@ -92,7 +93,7 @@ def test_row_mask_quirk_survives_the_fusion():
     m[0, 0, 20:] = 0
     x2 = x.clone()
     x2[0, 0, 25] += 1.0  # a padded position of news 0
-    with torch.no_grad():
+    with torch.no_grad(), hip.knobs(XNRS_NEWS_FUSED="2"):
         y, _ = enc((x.to(DEV), m.to(DEV)))
         y2, _ = enc((x2.to(DEV), m.to(DEV)))
         yo2, _ = O.text_encoder(x2, m, sd, h)
@@ -106,7 +107,7 @@ def test_shapes_outside_the_fused_range_take_the_pipeline():
         enc, sd = build(S, D, h, 32, 7300 + S)
         rng = synth.rng_for(8300 + D)
         x, m = synth.token_block(rng, 1, 3, S, D, min_len=2)
-        with torch.no_grad():
+        with torch.no_grad(), hip.knobs(XNRS_NEWS_FUSED="2"):
             (y, _), used = stages_used(lambda: enc((x.to(DEV), m.to(DEV))))
             yo, _ = O.text_encoder(x, m, sd, h)
         assert "news_fused" not in used and "qkv_gemm" in used
@@ -124,10 +125,15 @@ def test_large_batch_properties_at_configs1():
     x, m = x.reshape(1, n, S, D), m.reshape(1, n, S, 1)
     perm = torch.randperm(n, device=DEV)
     with torch.no_grad():
-        y, hm = enc((x, m))
-        yp, _ = enc((x[:, perm], m[:, perm]))
-        y1, _ = enc((x[:, 5:6], m[:, 5:6]))
-        y2, _ = enc((x[:, 4:6], m[:, 4:6]))
+        (y, hm), used = stages_used(lambda: enc((x, m)))
+        assert "news_fused" in used  # the default dispatch takes the fused kernel at this size
+        (ys, _), used_s = stages_used(lambda: enc((x[:, :100], m[:, :100])))
+        assert "news_fused" not in used_s  # ... and the pipeline for a hundred news
+        H.assert_close(ys, y[:, :100], tol=2e-5, what="pipeline (100 news) vs fused (1024 news)")
+        with hip.knobs(XNRS_NEWS_FUSED="2"):
+            yp, _ = enc((x[:, perm], m[:, perm]))
+            y1, _ = enc((x[:, 5:6], m[:, 5:6]))
+            y2, _ = enc((x[:, 4:6], m[:, 4:6]))
     assert torch.isfinite(y).all()
     assert torch.equal(yp, y[:, perm])
     assert torch.equal(y1[0, 0], y[0, 5]) and torch.equal(y2[0, 1], y[0, 5])

@@ -13,8 +13,10 @@ import bench  # noqa: E402
 from xnrs_amd import hip, synth  # noqa: E402
 
 dev = torch.device("cuda", 0)
-n_news = int(os.environ.get("N_NEWS", "1024"))
-for (S, D, h) in ((30, 300, 15), (30, 320, 16), (20, 320, 16), (32, 320, 16)):
+shapes = [(1024, 30, 300, 15), (1024, 30, 320, 16), (1024, 20, 320, 16), (1024, 32, 320, 16)]
+if os.environ.get("NF_SWEEP"):  # dispatch-rule sweep: news count and title length
+    shapes = [(n, 30, 320, 16) for n in (64, 256, 512, 2048, 8192, 28160)] + [(1024, S, 320, 16) for S in (16, 22, 24, 26, 28)]
+for (n_news, S, D, h) in shapes:
     w = dict(B=1, H=1, C=1, S=S, D=D, h=h, E=256 if D != 300 else 240, A=256)
     model, _ = bench.build_model(w, dev)
     gen = torch.Generator(device=dev)

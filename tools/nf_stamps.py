@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from xnrs_amd import hip  # noqa: E402
 
-hip.LIB_PATH = os.path.join(ROOT, "xnrs_amd", "libxnrs_hip_stamps.so")  # before the first hip.lib()
+hip.LIB_PATH = os.path.join(ROOT, "xnrs_amd", os.environ.get("NF_LIB", "libxnrs_hip_stamps.so"))  # before the first hip.lib()
 import bench  # noqa: E402
 from xnrs_amd import synth  # noqa: E402
 

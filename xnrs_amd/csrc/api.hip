@@ -205,9 +205,13 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
 
   // Short sequences: attention + additive pooling of ALL sequences in one launch (news_fused.hip); only the pooled
   // vectors leave the CU.  Inference only (nothing is saved for a backward), fp32 arithmetic only.
+  // Dispatch (measured, tools/bench_news_fused.py at D = 320): a workgroup owns 2 news padded to 32 token rows each and
+  // one CU, so the kernel wins from ~26 tokens (<= 19 % padding) and ~400 news (most CUs busy) upwards: 1024 x 30:
+  // 326 vs 376 us, 28 160 x 30: 8.2 vs 9.0 ms; 256 x 30: 176 vs 152 us, 1024 x 20: 318 vs 270 us.
+  // XNRS_NEWS_FUSED=2 forces it for every eligible shape (tests), 0 turns it off.
   const bool fused = att && additive && !train && !a_out && att->dropout_p == 0.f && gemm_mode() == 0 &&
                      knobs().news_fused && news_fused_plan(L, D, att->n_heads, A, nullptr) &&
-                     (D / att->n_heads) * att->n_heads == D;
+                     (D / att->n_heads) * att->n_heads == D && (knobs().news_fused == 2 || (L >= 26 && n_seq >= 384));
   if (fused) {
     NewsFusedArgs f{};
     f.x = x; f.ids = ids; f.mask = m;

@@ -620,7 +620,7 @@ static Knobs read_knobs() {
   k.mha_lds = (int)num("XNRS_MHA_LDS", -1);
   k.mha_headwave = num("XNRS_MHA_HEADWAVE", 1) != 0;
   k.mha_bwd_fused = num("XNRS_MHA_BWD_FUSED", 1) != 0;
-  k.news_fused = num("XNRS_NEWS_FUSED", 1) != 0;
+  k.news_fused = (int)num("XNRS_NEWS_FUSED", 1);
   const long long m = num("XNRS_GEMM_MODE", 0);
   k.gemm_mode_init = (m >= 0 && m <= 2) ? (int)m : 0;
   return k;

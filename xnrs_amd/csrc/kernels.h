@@ -24,7 +24,8 @@ struct Knobs {
   int mha_lds = -1;             // XNRS_MHA_LDS=0|1 force / forbid the LDS-staged attention kernel; -1 = by shape
   int mha_headwave = 1;         // XNRS_MHA_HEADWAVE=0: generic attention kernel only
   int mha_bwd_fused = 1;        // XNRS_MHA_BWD_FUSED=0: two-kernel attention backward
-  int news_fused = 1;           // XNRS_NEWS_FUSED=0: never use the fused short-title news encoder (news_fused.hip)
+  int news_fused = 1;           // XNRS_NEWS_FUSED=0|2: never / whenever eligible use the fused short-title news encoder
+                                // (news_fused.hip); 1 = where it is faster (S >= 26, >= 384 news)
   int gemm_mode_init = 0;       // XNRS_GEMM_MODE=0|1|2: initial forward-GEMM arithmetic (see gemm_mode())
 };
 const Knobs& knobs();
