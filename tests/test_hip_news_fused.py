@@ -55,8 +55,13 @@ def test_fused_equals_oracle_and_unfused(shape):
     x, m = synth.token_block(rng, 1, n, S, D, min_len=1, full_pad_prob=0.2)
     xd, md = x.to(DEV), m.to(DEV)
     with torch.no_grad():
-        with hip.knobs(XNRS_NEWS_FUSED="2"):  # "2": whenever eligible (the default dispatch wants >= 26 tokens, >= 384 news)
+        # "2": whenever eligible (the default dispatch wants >= 26 tokens and >= 192 news); both workgroup shapes
+        with hip.knobs(XNRS_NEWS_FUSED="2", XNRS_NEWS_FUSED_NPW="2"):
             (y, hm), used = stages_used(lambda: enc((xd, md)))
+        with hip.knobs(XNRS_NEWS_FUSED="2", XNRS_NEWS_FUSED_NPW="1"):
+            ya, hma = enc((xd, md))
+        H.assert_close(ya, y, tol=2e-6, what="1 news per workgroup vs 2")
+        assert torch.equal(hma, hm)
         assert "news_fused" in used and not (used & {"qkv_gemm", "attention_core", "out_gemm", "fc1_tanh_gemm", "pool"}), used
         assert "head_gemms" in used  # the MLP head stays a GEMM pair over all news
         with hip.knobs(XNRS_NEWS_FUSED="0"):

@@ -205,13 +205,15 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
 
   // Short sequences: attention + additive pooling of ALL sequences in one launch (news_fused.hip); only the pooled
   // vectors leave the CU.  Inference only (nothing is saved for a backward), fp32 arithmetic only.
-  // Dispatch (measured, tools/bench_news_fused.py at D = 320): a workgroup owns 2 news padded to 32 token rows each and
-  // one CU, so the kernel wins from ~26 tokens (<= 19 % padding) and ~400 news (most CUs busy) upwards: 1024 x 30:
-  // 326 vs 376 us, 28 160 x 30: 8.2 vs 9.0 ms; 256 x 30: 176 vs 152 us, 1024 x 20: 318 vs 270 us.
-  // XNRS_NEWS_FUSED=2 forces it for every eligible shape (tests), 0 turns it off.
+  // Dispatch (measured, tools/bench_news_fused.py at D = 320; profiles/r02_news_fused_dispatch_sweep.txt): a workgroup owns
+  // news padded to 32 token rows each, so the kernel wins from ~26 tokens (<= 19 % padding) upwards and once there are
+  // enough news to fill the CUs -- with 2 news per workgroup (every weight fragment feeds 4 row tiles) from 512 news,
+  // with 1 news per workgroup (twice the workgroups, two per CU) from ~200: 1024 x 30 tokens: 326 vs 374 us for the
+  // six-launch pipeline, 28 160 x 30: 8.2 vs 9.0 ms, 256 x 30: 116 vs 151 us; 64 x 30: 112 vs 94 us, 1024 x 20: 319 vs
+  // 271 us.  XNRS_NEWS_FUSED=2 forces it for every eligible shape (tests), 0 turns it off.
   const bool fused = att && additive && !train && !a_out && att->dropout_p == 0.f && gemm_mode() == 0 &&
                      knobs().news_fused && news_fused_plan(L, D, att->n_heads, A, nullptr) &&
-                     (D / att->n_heads) * att->n_heads == D && (knobs().news_fused == 2 || (L >= 26 && n_seq >= 384));
+                     (D / att->n_heads) * att->n_heads == D && (knobs().news_fused == 2 || (L >= 26 && n_seq >= 192));
   if (fused) {
     NewsFusedArgs f{};
     f.x = x; f.ids = ids; f.mask = m;
@@ -224,6 +226,7 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
     f.hm = m ? hm : nullptr;
     f.n_seq = n_seq;
     f.S = L; f.D = D; f.n_heads = att->n_heads; f.d_k = D / att->n_heads; f.A = A; f.scaled = att->scaled;
+    f.npw = knobs().news_fused_npw ? knobs().news_fused_npw : (n_seq < 512 ? 1 : 2);
     const double fl = (double)n_seq * (8.0 * L * D * D + 4.0 * L * L * D + 2.0 * L * D * A + 2.0 * L * (A + D));
     ProfScope ps(6, fl, stream);
     XNRS_TRY(launch_news_fused(f, stream));

@@ -621,6 +621,7 @@ static Knobs read_knobs() {
   k.mha_headwave = num("XNRS_MHA_HEADWAVE", 1) != 0;
   k.mha_bwd_fused = num("XNRS_MHA_BWD_FUSED", 1) != 0;
   k.news_fused = (int)num("XNRS_NEWS_FUSED", 1);
+  k.news_fused_npw = (int)num("XNRS_NEWS_FUSED_NPW", 0);
   const long long m = num("XNRS_GEMM_MODE", 0);
   k.gemm_mode_init = (m >= 0 && m <= 2) ? (int)m : 0;
   return k;

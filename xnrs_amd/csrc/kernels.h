@@ -25,7 +25,8 @@ struct Knobs {
   int mha_headwave = 1;         // XNRS_MHA_HEADWAVE=0: generic attention kernel only
   int mha_bwd_fused = 1;        // XNRS_MHA_BWD_FUSED=0: two-kernel attention backward
   int news_fused = 1;           // XNRS_NEWS_FUSED=0|2: never / whenever eligible use the fused short-title news encoder
-                                // (news_fused.hip); 1 = where it is faster (S >= 26, >= 384 news)
+                                // (news_fused.hip); 1 = where it is faster (S >= 26, >= 192 news)
+  int news_fused_npw = 0;       // XNRS_NEWS_FUSED_NPW=1|2 force the news per workgroup of the fused encoder; 0 = by batch size
   int gemm_mode_init = 0;       // XNRS_GEMM_MODE=0|1|2: initial forward-GEMM arithmetic (see gemm_mode())
 };
 const Knobs& knobs();
@@ -179,6 +180,7 @@ struct NewsFusedArgs {
   float* hm;           // nullable [n_seq]: clamp(sum mask, 0, 1)
   int64_t n_seq;
   int32_t S, D, n_heads, d_k, A, scaled;
+  int32_t npw;         // news per workgroup: 2 (default, 0 means 2) or 1
 };
 struct NewsFusedPlan {
   int npw, hg, lq, ly;  // news per workgroup, heads per group, LDS row strides of the Q|K|V and Y images
@@ -187,7 +189,7 @@ struct NewsFusedPlan {
   size_t img_bytes;       // caller-provided workspace for the fragment-ordered weight images
 };
 // does the fused kernel cover this shape (and with which plan)?
-bool news_fused_plan(int S, int D, int n_heads, int A, NewsFusedPlan* plan);
+bool news_fused_plan(int S, int D, int n_heads, int A, NewsFusedPlan* plan, int npw = 2);
 size_t news_fused_img_bound_bytes(int S, int D, int A);  // >= img_bytes for every n_heads; 0: no head count is eligible
 hipError_t launch_news_fused(const NewsFusedArgs& a, hipStream_t stream);
 

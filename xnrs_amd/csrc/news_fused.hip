@@ -43,8 +43,9 @@ namespace xnrs {
 
 namespace {
 
-constexpr int NF_NPW = 2;     // news per workgroup
-constexpr int NF_TR = 4;      // 16-row tiles per workgroup (32 virtual rows per news)
+// news per workgroup: a template parameter.  2: one workgroup per CU, every weight fragment feeds 4 row tiles;
+// 1: two workgroups per CU (<= 128 VGPRs, ~70 KB LDS) whose barrier / softmax / epilogue phases overlap each other's
+// MFMA loops, at twice the weight traffic per news.
 constexpr int NF_TF = 2;      // Q/K/V projection: 16-feature tiles per wave, 8 waves  (<= 256 columns per head group)
 constexpr int NF_TY = 5;      // out-projection: tiles per wave, 4 feature waves x 2 row waves  (D <= 320)
 constexpr int NF_TA = 2;      // fc1: tiles per wave, 8 waves  (A <= 256)
@@ -212,10 +213,11 @@ constexpr int NF_NSTAMP = 32;
     mma(IC<0>{}, IC<3>{});                                          \
   }
 
-template <int DK4>
-__global__ __launch_bounds__(NF_THREADS, 2) void news_fused_kernel(NewsFusedArgs a, NfImg im, const float* __restrict__ img, int HG,
+template <int DK4, int NPW>
+__global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kernel(NewsFusedArgs a, NfImg im, const float* __restrict__ img, int HG,
                                                                    int LQ, int LY) {
-  constexpr int NPW = NF_NPW, TR = NF_TR, TF = NF_TF, TY = NF_TY, TA = NF_TA;
+  constexpr int TR = 2 * NPW, TRC = NPW;  // 16-row tiles per workgroup (32 virtual rows per news); per wave in (c)
+  constexpr int TF = NF_TF, TY = NF_TY, TA = NF_TA;
   constexpr int dk = 4 * DK4;  // head width: compile-time, so the attention core is one straight run of MFMAs
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int S = a.S, D = a.D, H = a.n_heads;
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(NF_THREADS, 2) void news_fused_kernel(NewsFusedArgs
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wf = wave & 3, wr = wave >> 2;  // out-projection: feature quarter, news
+  const int wf = wave & 3, wr = wave >> 2;  // out-projection: feature quarter, row half (NPW = 2: news wr)
   const int c = lane & 15, g = lane >> 4;
   const int64_t news0 = (int64_t)blockIdx.x * NPW;
 
@@ -257,21 +259,22 @@ __global__ __launch_bounds__(NF_THREADS, 2) void news_fused_kernel(NewsFusedArgs
     lds_ok[rt] = sp < S;
     prow[rt] = (rt >> 1) * S + (sp < S ? sp : S - 1);
   }
-  // the two row tiles of news `wr` (out-projection)
-  int prow_c[2];
-  bool ok_c[2];
+  // the row tiles wr * TRC .. of the out-projection
+  int prow_c[TRC];
+  bool ok_c[TRC];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int sp = i * 16 + c;
+  for (int i = 0; i < TRC; ++i) {
+    const int rt = wr * TRC + i;
+    const int sp = (rt & 1) * 16 + c;
     ok_c[i] = sp < S;
-    prow_c[i] = wr * S + (sp < S ? sp : S - 1);
+    prow_c[i] = (rt >> 1) * S + (sp < S ? sp : S - 1);
   }
 
-  f32x4 yacc[TY][2];
+  f32x4 yacc[TY][TRC];
 #pragma unroll
   for (int t = 0; t < TY; ++t)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) yacc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < TRC; ++i) yacc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = im.nk;
   const float* imgl = img + lane * 4;  // this lane's 16 bytes of every weight fragment
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(NF_THREADS, 2) void news_fused_kernel(NewsFusedArgs
         int kc = ks * 16 + 4 * g;
         if (kc > D - 4) kc = D - 4;  // k tail: the weight image is zero there, the read only has to stay inside the row
 #pragma unroll
-        for (int rt = 2 * h; rt < 2 * h + 2; ++rt) fb[st][rt] = *reinterpret_cast<const f32x4*>(&r1[prow[rt] * LY + kc]);
+        for (int rt = NPW * h; rt < NPW * h + NPW; ++rt) fb[st][rt] = *reinterpret_cast<const f32x4*>(&r1[prow[rt] * LY + kc]);
       };
       auto mma = [&](auto ST, auto J) {
         constexpr int st = decltype(ST)::value, j = decltype(J)::value;
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(NF_THREADS, 2) void news_fused_kernel(NewsFusedArgs
     {
       const float* wc = imgl + im.off_wo(grp) + (size_t)wf * TY * NF_FRAG;
       const int nkc = (NW + 15) >> 4;
-      f32x4 fa[2][TY], fb[2][2];
+      f32x4 fa[2][TY], fb[2][TRC];
       auto load_w = [&](auto ST, int ks) {
         constexpr int st = decltype(ST)::value;
         const float* wk = wc + (size_t)ks * (4 * TY * NF_FRAG);
@@ -474,14 +477,14 @@ __global__ __launch_bounds__(NF_THREADS, 2) void news_fused_kernel(NewsFusedArgs
       auto load_b = [&](auto ST, int ks, auto HALF) {
         constexpr int st = decltype(ST)::value, h = decltype(HALF)::value;
         const int k = ks * 16 + 4 * g;  // k < NW + 16 <= LQ; columns past NW meet zeros of the image
-        fb[st][h] = *reinterpret_cast<const f32x4*>(&r2[prow_c[h] * LQ + k]);
+        if (h < TRC) fb[st][h] = *reinterpret_cast<const f32x4*>(&r2[prow_c[h < TRC ? h : 0] * LQ + k]);
       };
       auto mma = [&](auto ST, auto J) {
         constexpr int st = decltype(ST)::value, j = decltype(J)::value;
 #pragma unroll
         for (int t = 0; t < TY; ++t)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < TRC; ++i)
             yacc[t][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[st][t][j], fb[st][i][j], yacc[t][i], 0, 0, 0);
       };
       NF_KLOOP(nkc)
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(NF_THREADS, 2) void news_fused_kernel(NewsFusedArgs
     if (d0 < D) {
       const f32x4 bv = *reinterpret_cast<const f32x4*>(img + im.off_bo() + (wf * TY + t) * 16 + 4 * g);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TRC; ++i)
         if (ok_c[i]) *reinterpret_cast<f32x4*>(&r1[prow_c[i] * LY + d0]) = yacc[t][i] + bv;
     }
   }
@@ -525,7 +528,7 @@ __global__ __launch_bounds__(NF_THREADS, 2) void news_fused_kernel(NewsFusedArgs
       int kc = ks * 16 + 4 * g;
       if (kc > D - 4) kc = D - 4;
 #pragma unroll
-      for (int rt = 2 * h; rt < 2 * h + 2; ++rt) fb[st][rt] = *reinterpret_cast<const f32x4*>(&r1[prow[rt] * LY + kc]);
+      for (int rt = NPW * h; rt < NPW * h + NPW; ++rt) fb[st][rt] = *reinterpret_cast<const f32x4*>(&r1[prow[rt] * LY + kc]);
     };
     auto mma = [&](auto ST, auto J) {
       constexpr int st = decltype(ST)::value, j = decltype(J)::value;
@@ -623,7 +626,8 @@ int stride8(int n) {  // smallest stride >= n with stride % 16 == 8: conflict-fr
 
 }  // namespace
 
-bool news_fused_plan(int S, int D, int n_heads, int A, NewsFusedPlan* plan) {
+bool news_fused_plan(int S, int D, int n_heads, int A, NewsFusedPlan* plan, int npw) {
+  if (npw != 1 && npw != 2) return false;
   if (S <= 0 || S > 32 || D < 4 || D % 4 != 0 || D > 16 * 4 * NF_TY || n_heads <= 0 || D % n_heads != 0) return false;
   const int dk = D / n_heads;
   if (dk % 4 != 0 || dk > 32 || A <= 0 || A > 16 * 8 * NF_TA) return false;
@@ -631,10 +635,10 @@ bool news_fused_plan(int S, int D, int n_heads, int A, NewsFusedPlan* plan) {
   if (hg > n_heads) hg = n_heads;
   if (hg < 1) return false;
   const int lq = stride8(3 * hg * dk), ly = stride8(D);
-  const size_t floats = (size_t)NF_NPW * S * (lq + ly) + 8 * NF_NPW * 32 + 2 * NF_NPW * 32;
+  const size_t floats = (size_t)npw * S * (lq + ly) + 8 * npw * 32 + 2 * npw * 32;
   if (floats * 4 > 160 * 1024) return false;
   if (plan) {
-    plan->npw = NF_NPW;
+    plan->npw = npw;
     plan->hg = hg;
     plan->lq = lq;
     plan->ly = ly;
@@ -658,7 +662,8 @@ size_t news_fused_img_bound_bytes(int S, int D, int A) {
 hipError_t launch_news_fused(const NewsFusedArgs& a, hipStream_t stream) {
   if (a.n_seq <= 0) return hipSuccess;
   NewsFusedPlan p;
-  if (!news_fused_plan(a.S, a.D, a.n_heads, a.A, &p) || a.d_k * a.n_heads != a.D) return hipErrorInvalidValue;
+  const int npw = a.npw == 1 ? 1 : 2;
+  if (!news_fused_plan(a.S, a.D, a.n_heads, a.A, &p, npw) || a.d_k * a.n_heads != a.D) return hipErrorInvalidValue;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   if (!al16(a.x) || !al16(a.wq) || !al16(a.wk) || !al16(a.wv) || !al16(a.wo) || !al16(a.w1) || !a.img || !al16(a.img))
     return hipErrorInvalidValue;
@@ -670,26 +675,33 @@ hipError_t launch_news_fused(const NewsFusedArgs& a, hipStream_t stream) {
   if (pe != hipSuccess) return pe;
   const int64_t grid = (a.n_seq + p.npw - 1) / p.npw;
   if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  // one instantiation per head width (d_k / 4 = 1 .. 8); each needs its dynamic-LDS limit raised once
-  static std::once_flag once[8];
-  static hipError_t attr_rc[8];
+  // one instantiation per head width (d_k / 4 = 1 .. 8) and news count; each needs its dynamic-LDS limit raised once
+  static std::once_flag once[8][2];
+  static hipError_t attr_rc[8][2];
   hipError_t rc = hipErrorInvalidValue;
-#define NF_CASE(Q)                                                                                                   \
-  case Q:                                                                                                            \
-    std::call_once(once[Q - 1], [] {                                                                                 \
-      attr_rc[Q - 1] = hipFuncSetAttribute(reinterpret_cast<const void*>(&news_fused_kernel<Q>),                     \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
-    });                                                                                                              \
-    if (attr_rc[Q - 1] != hipSuccess) return attr_rc[Q - 1];                                                         \
-    hipLaunchKernelGGL((news_fused_kernel<Q>), dim3((unsigned)grid), dim3(NF_THREADS), p.lds_bytes, stream, a, im, a.img, \
-                       p.hg, p.lq, p.ly);                                                                            \
-    rc = hipGetLastError();                                                                                          \
+#define NF_LAUNCH(Q, N)                                                                                                    \
+  std::call_once(once[Q - 1][N - 1], [] {                                                                                  \
+    attr_rc[Q - 1][N - 1] = hipFuncSetAttribute(reinterpret_cast<const void*>(&news_fused_kernel<Q, N>),                   \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                   \
+  });                                                                                                                      \
+  if (attr_rc[Q - 1][N - 1] != hipSuccess) return attr_rc[Q - 1][N - 1];                                                   \
+  hipLaunchKernelGGL((news_fused_kernel<Q, N>), dim3((unsigned)grid), dim3(NF_THREADS), p.lds_bytes, stream, a, im, a.img, \
+                     p.hg, p.lq, p.ly);                                                                                    \
+  rc = hipGetLastError();
+#define NF_CASE(Q)             \
+  case Q:                      \
+    if (npw == 1) {            \
+      NF_LAUNCH(Q, 1)          \
+    } else {                   \
+      NF_LAUNCH(Q, 2)          \
+    }                          \
     break;
   switch (a.d_k / 4) {
     NF_CASE(1) NF_CASE(2) NF_CASE(3) NF_CASE(4) NF_CASE(5) NF_CASE(6) NF_CASE(7) NF_CASE(8)
     default: break;
   }
 #undef NF_CASE
+#undef NF_LAUNCH
   return rc;
 }
 
