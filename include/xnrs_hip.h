@@ -216,6 +216,14 @@ int32_t xnrs_embedding_linear_bwd(const float *table, const int32_t *ids, const 
 int32_t xnrs_dot_scoring_bwd(const float *u, const float *c, const float *dr, float *du, float *dc, int64_t B,
                              int32_t C, int32_t E, void *stream);
 
+/* ---- NewsRecDataset.__getitem__ look-ups + torch.cat (xnrs/data/dataset.py:63-85,97-109) as a device copy ----
+ * out[i, :] = table[ids[i], :], i < n, rows of row_floats fp32 (a whole news block: S*D token floats, or S mask
+ * floats).  For consumers that need the dense batch (input gradients of the explainer, explain.py:160-166); the
+ * encoders gather inside their first load and never call this.  HBM-bound; 16-byte streaming accesses when
+ * row_floats % 4 == 0 and both pointers are 16-byte aligned. */
+int32_t xnrs_gather_rows(const float *table, const int32_t *ids, float *out, int64_t n, int64_t row_floats,
+                         void *stream);
+
 /* ---- device-side batch assembly and evaluation -----------------------
  * Click histories / positives / negatives live on the device as CSR arrays of ROWS into the resident news
  * table ([n_rows,S,D] + mask; `pad_row` = the empty slot: all-zero tokens and mask, dataset.py:82-85).

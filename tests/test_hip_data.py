@@ -155,3 +155,28 @@ def test_dedup_equals_plain_id_path():
     r = model.forward_ids(dstore.x, dstore.m, hist, cand, dedup=True)
     r.sum().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in model.named_parameters() if "dummy" not in n)
+
+
+def test_gather_rows_equals_the_dataset_materialisation():
+    """NewsStore.gather (xnrs_gather_rows) = what NewsRecDataset.__getitem__ would have concatenated on the host
+    (oracle: data_oracle.materialise, pinned to the real dataset by tests/golden/data.npz), bit for bit -- vector and
+    scalar code paths (S*D % 4 == 0 with S % 4 != 0 for the mask), repeated and empty-slot rows, 2-d row arrays."""
+    news_feat, sessions, store, beh = setup()
+    dstore = store.to(DEV)
+    rng = synth.rng_for(911)
+    rows = torch.from_numpy(rng.integers(0, len(store.ids) + 1, size=(3, 7)).astype(np.int32))
+    rows[0, 0] = 0  # the empty slot
+    x, m = dstore.gather(rows.to(DEV))
+    hx, hm = DO.materialise(store.x.numpy(), store.m.numpy(), rows.reshape(-1).tolist())
+    assert x.shape == (3, 7) + tuple(store.x.shape[1:]) and m.shape == (3, 7, store.x.shape[1], 1)
+    assert np.array_equal(x.cpu().numpy().reshape(hx.shape), hx) and np.array_equal(m.cpu().numpy().reshape(hm.shape), hm)
+    # a big block shape (150 KB rows, the shipped token shape) against torch indexing
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(1)
+    tx, tm = synth.device_tokens(gen, 64, 50, 768, DEV)
+    big = NewsStore(tx, tm.reshape(64, 50), list(range(63)))
+    ids = torch.randint(0, 64, (200,), generator=gen, device=DEV, dtype=torch.int32)
+    gx, gm = big.gather(ids)
+    assert torch.equal(gx, tx[ids.long()]) and torch.equal(gm, tm[ids.long()])
+    with pytest.raises(Exception):
+        store.gather(rows)  # host tensors fail loudly

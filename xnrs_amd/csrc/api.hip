@@ -1045,6 +1045,12 @@ int32_t xnrs_assemble_eval_batch(const int64_t* sess, int64_t B, const int64_t* 
   return hip_rc(launch_assemble_eval(a, (hipStream_t)stream));
 }
 
+int32_t xnrs_gather_rows(const float* table, const int32_t* ids, float* out, int64_t n, int64_t row_floats, void* stream) {
+  if (n == 0) return XNRS_OK;
+  if (!table || !ids || !out || n < 0 || row_floats <= 0) return XNRS_EINVAL;
+  return hip_rc(launch_gather_rows(table, ids, out, n, row_floats, (hipStream_t)stream));
+}
+
 int32_t xnrs_score_csr(const float* vecs, const int32_t* cand_rows, const int32_t* cand_sess, const float* u, float* r,
                        int64_t n_cand, int32_t E, int32_t relu, void* stream) {
   if (n_cand == 0) return XNRS_OK;

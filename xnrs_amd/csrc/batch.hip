@@ -9,6 +9,10 @@
 //   score_csr      : DotScoring over a CSR candidate list against pre-encoded news vectors
 //                    (scoring.py:23 applied per impression, training.py:194-203 with batch_size 1).
 //   rank_metrics   : xnrs/evaluation/metrics.py:9-64 per impression (nDCG@k, RR, CTR@k, AUC, acc/rec/prec).
+//   gather_rows    : the dict look-ups + torch.cat of NewsRecDataset.__getitem__ (dataset.py:63-85,97-109) as a
+//                    device copy: out[i] = table[ids[i]] for whole news blocks (S*D floats, 150 KB at the shipped
+//                    shape) -- the materialised batch for consumers that need dense token tensors (input gradients
+//                    of the explainer, explain.py:160-166); the encoders themselves gather inside their first load.
 #include "kernels.h"
 
 namespace xnrs {
@@ -185,6 +189,47 @@ hipError_t launch_rank_metrics(const float* score, const float* target, const in
                                hipStream_t stream) {
   if (B <= 0) return hipSuccess;
   hipLaunchKernelGGL(rank_metrics_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, score, target, off, out, B);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- gather_rows (HBM-bound block copy)
+// one workgroup per (output row, 16-KB piece): 4 independent 16-byte loads per thread in flight, streaming
+// (nontemporal) on both sides -- every byte is touched once
+template <bool VEC>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids,
+                                                           float* __restrict__ out, int64_t row_floats, int pieces) {
+  const int64_t row = blockIdx.x / pieces;
+  const int piece = (int)(blockIdx.x - row * pieces);
+  const int64_t src = (int64_t)ids[row] * row_floats, dst = row * row_floats;
+  if (VEC) {
+    const int64_t n4 = row_floats >> 2;
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(table + src);
+    f32x4* d4 = reinterpret_cast<f32x4*>(out + dst);
+    const int64_t base = (int64_t)piece * 1024 + threadIdx.x;
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (base + 256 * u < n4) v[u] = __builtin_nontemporal_load(s4 + base + 256 * u);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (base + 256 * u < n4) __builtin_nontemporal_store(v[u], d4 + base + 256 * u);
+  } else {
+    const int64_t base = (int64_t)piece * 4096 + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (base + 256 * u < row_floats) out[dst + base + 256 * u] = table[src + base + 256 * u];
+  }
+}
+
+hipError_t launch_gather_rows(const float* table, const int32_t* ids, float* out, int64_t n, int64_t row_floats,
+                              hipStream_t stream) {
+  if (n <= 0 || row_floats <= 0) return hipSuccess;
+  const bool vec = row_floats % 4 == 0 && ((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  const int64_t pieces = (row_floats + 4095) / 4096;  // 16 KB per workgroup
+  if (n * pieces > 0x7fffffffLL) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)(n * pieces));
+  if (vec) hipLaunchKernelGGL((gather_rows_kernel<true>), grid, dim3(256), 0, stream, table, ids, out, row_floats, (int)pieces);
+  else hipLaunchKernelGGL((gather_rows_kernel<false>), grid, dim3(256), 0, stream, table, ids, out, row_floats, (int)pieces);
   return hipGetLastError();
 }
 

@@ -61,9 +61,15 @@ __device__ __attribute__((aligned(16))) float g_zero_line[4] = {0.f, 0.f, 0.f, 0
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned BUF_OOB = 0x40000000u;
 
-template <int TM, int TN, bool A_COL, bool B_KN, bool VEC, int PIPE, int BK, bool BUF = false, int MINW = 2>
+// GATH (with BUF): the rows of A are gathered (or A is too large for a buffer descriptor): A is read through per-thread
+// 64-bit row pointers, UNCONDITIONALLY -- rows past M are clamped to row M-1 (their results are never stored) and the k
+// tail is clamped to K-4 (it meets the zeros the bounds check returns for B) -- while B keeps the raw buffer loads.
+// No address selects and no zero line: 4 VGPRs more than the pure buffer-load kernel, still 4 workgroups per CU (the
+// first gather variant selected between row pointer and zero line per load: 139 VGPRs, 45 spills, 3 workgroups/CU, 5 %).
+template <int TM, int TN, bool A_COL, bool B_KN, bool VEC, int PIPE, int BK, bool BUF = false, int MINW = 2, bool GATH = false>
 __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_tiles, int n_tiles_seg, int gn) {
   static_assert(!BUF || (!A_COL && !B_KN && VEC), "buffer loads are implemented for the forward layout");
+  static_assert(!GATH || BUF, "the gathered-A variant keeps buffer loads for B");
   constexpr int BM = 64 * TM, BN = 64 * TN;
   // k-contiguous LDS tile rows: BK = 32 -> padded to 36 floats (conflict-free ds_read_b128, measured
   // SQ_LDS_BANK_CONFLICT = 0); BK = 16 -> 64-B rows, UNPADDED, with the 16-byte chunk index XOR-swizzled by
@@ -132,12 +138,21 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
   unsigned offA[AR], offB[BR];  // BUF: byte offset of (row, chunk lc), or BUF_OOB
   __amdgpu_buffer_rsrc_t rsA, rsB;
   if constexpr (BUF) {
-    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, (int)(a.M * a.lda * 4), 0x00020000);
+    if constexpr (!GATH) rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, (int)(a.M * a.lda * 4), 0x00020000);
     rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, (int)((int64_t)a.Nseg * a.ldw * 4), 0x00020000);
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const int64_t gr = m0 + lr + RPP * i;
-      offA[i] = gr < a.M ? (unsigned)((gr * a.lda + 4 * lc) * 4) : BUF_OOB;
+      if constexpr (GATH) {
+        int64_t src = gr < a.M ? gr : a.M - 1;
+        if (a.gather_ids) {
+          const int64_t n = src / a.gather_S;
+          src = (int64_t)a.gather_ids[n] * a.gather_S + (src - n * a.gather_S);
+        }
+        pa[i] = a.A + src * a.lda + 4 * lc;
+      } else {
+        offA[i] = gr < a.M ? (unsigned)((gr * a.lda + 4 * lc) * 4) : BUF_OOB;
+      }
     }
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
@@ -182,10 +197,16 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
     if constexpr (BUF) {
       const unsigned sel = (k0 + 4 * lc < kend) ? 0u : BUF_OOB;  // k tail of the last tile
       const int soff = (int)(k0 * 4);
+      int64_t ka = k0;  // GATH: clamp the k tail (B returns zeros there)
+      if constexpr (GATH) {
+        if (ka + 4 * lc > kend - 4) ka = kend - 4 - 4 * lc;
+      }
 #pragma unroll
       for (int i = 0; i < AR; ++i)
-        if (only < 0 || only == i)
-          ra[p][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)(offA[i] | sel), soff, 0));
+        if (only < 0 || only == i) {
+          if constexpr (GATH) ra[p][i] = *reinterpret_cast<const f32x4*>(pa[i] + ka);
+          else ra[p][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)(offA[i] | sel), soff, 0));
+        }
 #pragma unroll
       for (int i = 0; i < BR; ++i)
         if (only < 0 || only == AR + i)
@@ -528,10 +549,16 @@ static hipError_t launch_cfg(const GemmArgs& a, bool vec, int nsplit, hipStream_
   // BK 16, registers capped for 4 workgroups per CU on the main tile.
   const int pipe = knobs().gemm_pipe;
   const int bk = knobs().gemm_bk;
-  const bool buf = knobs().gemm_buf && vec && !a.gather_ids && a.M * a.lda * 4 <= (int64_t)BUF_OOB &&
-                   (int64_t)a.Nseg * a.ldw * 4 <= (int64_t)BUF_OOB;
+  const bool bufB = knobs().gemm_buf && vec && (int64_t)a.Nseg * a.ldw * 4 <= (int64_t)BUF_OOB;
+  const bool buf = bufB && !a.gather_ids && a.M * a.lda * 4 <= (int64_t)BUF_OOB;
+  // gathered rows / an A operand beyond the 1-GB descriptor window: pointers for A, buffer loads for B (K >= 4: the
+  // k-tail clamp reads K-4 .. K-1)
+  const bool gath = bufB && !buf && !a.c_scatter && a.K >= 4;
 #define XNRS_LAUNCH(VECV, PIPEV, BKV, BUFV, MINWV)                                                                  \
   hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, A_COL, B_KN, VECV, PIPEV, BKV, BUFV, MINWV>), g, dim3(256), 0, stream, a, \
+                     (int)m_tiles, n_tiles_seg, gn)
+#define XNRS_LAUNCH_GATH(MINWV)                                                                                       \
+  hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, A_COL, B_KN, true, 5, 16, true, MINWV, true>), g, dim3(256), 0, stream, a, \
                      (int)m_tiles, n_tiles_seg, gn)
   if (!vec) XNRS_LAUNCH(false, 1, 32, false, 2);
   else if constexpr (TM == 2 && TN == 2 && !A_COL && !B_KN) {  // forward main tile: all variants are built
@@ -541,17 +568,20 @@ static hipError_t launch_cfg(const GemmArgs& a, bool vec, int nsplit, hipStream_
     else if (pipe == 5 && buf) XNRS_LAUNCH(true, 5, 32, true, 2);
     else if (pipe == 5) XNRS_LAUNCH(true, 5, 32, false, 2);
     else if (buf) XNRS_LAUNCH(true, 5, 16, true, 4);
-    else XNRS_LAUNCH(true, 5, 16, false, 3);  // 64-bit row pointers (gather / >1 GB operands): 139 VGPRs, 45 spills
-                                               // under the 128 cap -> 3 workgroups per CU instead
+    else if (gath) XNRS_LAUNCH_GATH(4);
+    else XNRS_LAUNCH(true, 5, 16, false, 3);  // pointers + zero-line selects on both operands (row scatter, > 1 GB
+                                               // weights): 139 VGPRs -> 3 workgroups per CU
   } else if constexpr (!A_COL && !B_KN) {
     // the smaller forward tiles use the main tile's configuration too (BK 16, registers capped for 4 WG/CU):
     // +19..25 % on the Q/K/V projection at D = 300 / 320 against BK 32 at 2 WG/CU
     if (buf) XNRS_LAUNCH(true, 5, 16, true, 4);
+    else if (gath) XNRS_LAUNCH_GATH(4);
     else XNRS_LAUNCH(true, 5, 16, false, 4);
   } else {
     XNRS_LAUNCH(true, 5, 32, false, 2);  // backward (k-major) layouts: BK 16 / 4 WG per CU measured no better
   }
 #undef XNRS_LAUNCH
+#undef XNRS_LAUNCH_GATH
   return hipGetLastError();
 }
 

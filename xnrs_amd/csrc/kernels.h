@@ -280,6 +280,9 @@ struct BatchArgs {
   int32_t* cand_sess_out;    // eval: [n_cand] impression index of every candidate
   float* targets_out;        // eval: [n_cand]
 };
+// out[i, :] = table[ids[i], :] for rows of row_floats floats (whole news blocks)
+hipError_t launch_gather_rows(const float* table, const int32_t* ids, float* out, int64_t n, int64_t row_floats,
+                              hipStream_t stream);
 hipError_t launch_assemble_train(const BatchArgs& a, hipStream_t stream);
 hipError_t launch_assemble_eval(const BatchArgs& a, hipStream_t stream);
 hipError_t launch_score_csr(const float* vecs, const int32_t* rows, const int32_t* sess, const float* u, float* r, int64_t n,

@@ -59,6 +59,21 @@ class NewsStore:
     def rows(self, news_ids: Sequence) -> List[int]:
         return [self.index[n] for n in news_ids]
 
+    def gather(self, rows: torch.Tensor):
+        """Dense (x:(*rows.shape,S,D), m:(*rows.shape,S,1)) for int32 table rows -- the tensors the reference's dataset
+        would have built on the host (dataset.py:63-85,97-109).  Only for consumers that need the batch itself (input
+        gradients of the explainer); the encoders take the rows directly (forward_ids)."""
+        if not self.x.is_cuda or not rows.is_cuda:
+            raise hip.XnrsHipError("NewsStore.gather: the table and the rows must live on the HIP device")
+        flat = rows.reshape(-1).to(torch.int32).contiguous()
+        n, (S, D) = flat.numel(), self.x.shape[1:]
+        x = torch.empty((n, S, D), dtype=torch.float32, device=self.x.device)
+        m = torch.empty((n, S), dtype=torch.float32, device=self.x.device)
+        st = hip.stream_ptr(self.x.device)
+        hip.check(hip.lib().xnrs_gather_rows(hip.ptr(self.x), hip.ptr(flat), hip.ptr(x), n, S * D, st), "xnrs_gather_rows(x)")
+        hip.check(hip.lib().xnrs_gather_rows(hip.ptr(self.m), hip.ptr(flat), hip.ptr(m), n, S, st), "xnrs_gather_rows(m)")
+        return x.reshape(*rows.shape, S, D), m.reshape(*rows.shape, S, 1)
+
     # ---- flat on-disk format: <path>.json (header) + <path>.x.f32 + <path>.m.u8 (+ <path>.<col>.i32)
     def save(self, path: str) -> None:
         x = self.x.detach().cpu().numpy()

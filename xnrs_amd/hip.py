@@ -29,7 +29,7 @@ SYMBOLS = (
     "xnrs_seq_encoder_saved_bytes", "xnrs_seq_encoder_fwd_train", "xnrs_seq_encoder_bwd_workspace_bytes",
     "xnrs_seq_encoder_bwd", "xnrs_seq_encoder_bwd_live", "xnrs_linear_bwd_workspace_bytes", "xnrs_linear_bwd",
     "xnrs_embedding_linear_bwd_workspace_bytes", "xnrs_embedding_linear_bwd", "xnrs_dot_scoring_bwd",
-    "xnrs_assemble_train_batch", "xnrs_assemble_eval_batch", "xnrs_score_csr", "xnrs_rank_metrics",
+    "xnrs_assemble_train_batch", "xnrs_assemble_eval_batch", "xnrs_score_csr", "xnrs_rank_metrics", "xnrs_gather_rows",
     "xnrs_infonce_saved_bytes", "xnrs_infonce_fwd", "xnrs_infonce_bwd",
 )
 POOL_NONE = -1
@@ -143,6 +143,8 @@ def lib():
     l.xnrs_assemble_train_batch.argtypes = [p, i64, p, p, p, p, p, p, i32, i32, i32, C.c_uint64, p, p, p]
     l.xnrs_assemble_eval_batch.restype = i32
     l.xnrs_assemble_eval_batch.argtypes = [p, i64, p, p, p, p, p, p, i32, i32, p, p, p, p, p, p]
+    l.xnrs_gather_rows.restype = i32
+    l.xnrs_gather_rows.argtypes = [p, p, p, i64, i64, p]
     l.xnrs_score_csr.restype = i32
     l.xnrs_score_csr.argtypes = [p, p, p, p, p, i64, i32, i32, p]
     l.xnrs_rank_metrics.restype = i32
