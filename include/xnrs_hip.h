@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define XNRS_ABI_VERSION 1
+#define XNRS_ABI_VERSION 2
 
 #define XNRS_OK 0
 #define XNRS_EINVAL (-1)     /* bad shape / NULL pointer */
@@ -64,11 +64,15 @@ typedef struct {
   int32_t hidden; /* A */
 } xnrs_additive_params;
 
-/* nn.Sequential(Linear(in,out), ReLU, Linear(out,out)) head
- * (news_encoding.py:25-31, user_encoding.py:30-34); biases may be NULL (bias=False) */
+/* nn.Sequential(Linear(in,out), activation, Linear(out,out)) head
+ * (news_encoding.py:25-31, user_encoding.py:30-34); biases may be NULL (bias=False).
+ * activation: XNRS_ACT_RELU (the reference's default nn.ReLU()), XNRS_ACT_TANH or XNRS_ACT_NONE -- the three the GEMM
+ * epilogue and its backward implement; the Python mirror refuses any other `activation` module (ABI version 2 added
+ * this field). */
 typedef struct {
   const float *w0, *b0, *w2, *b2;
   int32_t out_features;
+  int32_t activation;
 } xnrs_head_params;
 
 int32_t xnrs_abi_version(void);
@@ -215,6 +219,9 @@ int32_t xnrs_embedding_linear_bwd(const float *table, const int32_t *ids, const 
 /* autograd of DotScoring.forward with normalize == 0 (scoring.py:23): du:(B,E), dc:(B,C,E), either nullable */
 int32_t xnrs_dot_scoring_bwd(const float *u, const float *c, const float *dr, float *du, float *dc, int64_t B,
                              int32_t C, int32_t E, void *stream);
+/* the same with normalize == 1 (scoring.py:20-22: u and c L2-normalised before the product); E <= 1024 */
+int32_t xnrs_dot_scoring_norm_bwd(const float *u, const float *c, const float *dr, float *du, float *dc, int64_t B,
+                                  int32_t C, int32_t E, void *stream);
 
 /* ---- NewsRecDataset.__getitem__ look-ups + torch.cat (xnrs/data/dataset.py:63-85,97-109) as a device copy ----
  * out[i, :] = table[ids[i], :], i < n, rows of row_floats fp32 (a whole news block: S*D token floats, or S mask

@@ -50,6 +50,10 @@ ENCODERS = {
     "user_nrms": dict(tower="user", B=3, N=25, D=256, h=16, A=256, E=256, att=True, pooler="additive", head=False, bias=True, seed=210),
     "user_std_head": dict(tower="user", B=3, N=7, D=32, h=4, A=256, E=32, att=False, pooler="additive", head=True, bias=False, seed=211),
     "user_mean": dict(tower="user", B=3, N=7, D=32, h=4, A=256, E=32, att=False, pooler="mean", head=False, bias=True, seed=212),
+    # shipped shapes (mind_small_*.yml: hist_len 25; BASELINE configs[2]: history 50): outputs only, inputs regenerate
+    "user_nrms_h50": dict(tower="user", B=2, N=50, D=256, h=16, A=256, E=256, att=True, pooler="additive", head=False, bias=True, seed=213),
+    "user_std_h25": dict(tower="user", B=2, N=25, D=256, h=16, A=256, E=256, att=False, pooler="additive", head=True, bias=False, seed=214),
+    "news_add_768": dict(tower="news", B=1, N=3, S=50, D=768, h=16, A=256, E=256, att=False, pooler="additive", head=True, bias=False, seed=206),
 }
 
 MODELS = {
@@ -60,6 +64,12 @@ MODELS = {
     "standard_bias": dict(model="standard", B=2, H=5, C=5, S=12, D=64, h=4, E=32, bias=True, seed=311),
     "base_tiny": dict(model="base", B=3, H=4, C=3, S=8, D=32, h=4, E=16, bias=False, seed=320),
     "naml_tiny": dict(model="NAML", B=2, H=4, C=3, S=8, D=32, h=4, E=16, bias=False, seed=330),
+    # the other models at the shipped token shape S=50, D=768, E=256 (config/mind_small_{CL,NAML}.yml; BASELINE configs[3],
+    # [4]) and NRMS at BASELINE configs[2]'s history of 50: outputs only (a few hundred floats each)
+    "standard_shipped": dict(model="standard", B=1, H=3, C=2, S=50, D=768, h=16, E=256, bias=False, seed=312, min_len=5),
+    "base_shipped": dict(model="base", B=1, H=3, C=2, S=50, D=768, h=16, E=256, bias=False, seed=321, min_len=5),
+    "naml_shipped": dict(model="NAML", B=1, H=3, C=2, S=50, D=768, h=16, E=256, bias=False, seed=331, min_len=5),
+    "nrms_h50": dict(model="NRMS", B=1, H=50, C=5, S=50, D=768, h=16, E=256, bias=False, seed=303, min_len=5),
 }
 
 LSTUR = dict(model="LSTUR", B=2, H=4, C=3, S=8, D=32, h=4, E=16, bias=False, seed=340)

@@ -226,6 +226,30 @@ def data_cases():
     return out
 
 
+def shipped_config_cases():
+    """The reference's make_model on its own shipped YAMLs (config/mind_small_{NRMS,CL,NAML}.yml): the flat cfg keys the
+    model constructors read (data: hyper-parameters) and the resulting state_dict key -> shape map + parameter count.
+    north_star: "drops into ... the NRMS/NAML/LSTUR configs unchanged".  mind_small_LSTUR.yml is recorded with the
+    exception the REFERENCE itself raises when it builds it (SURVEY.md finding 5)."""
+    import yaml
+    read = ("model", "scoring", "total_emb_dim", "title_emb_dim", "bias", "n_heads", "d_backbone", "p_dropout", "cat_emb_dim",
+            "sub_emb_dim", "n_categories", "n_subcategories", "catg_features", "text_features", "user_features", "add_features",
+            "hist_len", "seq_len", "n_users", "st_hist_len", "base_model")
+    out = {}
+    for name in ("mind_small_NRMS", "mind_small_CL", "mind_small_NAML", "mind_small_LSTUR"):
+        full = yaml.safe_load(open(f"{REF}/config/{name}.yml"))
+        cfg = {k: full[k] for k in read if k in full}
+        entry = {"cfg": cfg}
+        try:
+            model = make_model(Cfg(full))
+            entry["state_dict"] = {k: list(v.shape) for k, v in model.state_dict().items()}
+            entry["n_params"] = int(sum(p.numel() for p in model.parameters()))
+        except Exception as e:  # noqa: BLE001
+            entry["reference_error"] = type(e).__name__
+        out[name] = entry
+    return out
+
+
 def error_cases():
     """Pin the reference's D % h != 0 failure (layers.py:111,133)."""
     mod = layers.MultiHeadAttention(16, 300)
@@ -250,6 +274,8 @@ def main():
     for g, d in groups.items():
         np.savez_compressed(os.path.join(HERE, f"{g}.npz"), **d)
         print(g, len(d), "arrays", sum(v.nbytes for v in d.values()), "bytes")
+    with open(os.path.join(HERE, "shipped_configs.json"), "w") as f:
+        json.dump(shipped_config_cases(), f, indent=1, sort_keys=True)
     meta = {"torch": torch.__version__, "numpy": np.__version__, "errors": error_cases()}
     with open(os.path.join(HERE, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1)

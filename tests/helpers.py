@@ -8,10 +8,17 @@ from xnrs_amd import synth
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-# The parity bar of BASELINE.json north_star: fp32 scores within 1e-4 relative of the reference
-# CPU path.  "Relative" is taken against the tensor's own scale (max |ref|), plus an elementwise
-# rtol, so that near-zero entries of a dot product are not held to an impossible bar.
+# The parity bar of BASELINE.json north_star: fp32 scores within 1e-4 relative of the reference CPU path.  Checked
+# two ways, both must hold:
+#   * per tensor:  max|d| <= tol * max|ref|
+#   * per element: |d_i| <= tol * |ref_i| + ATOL_FRAC * tol * max|ref|
+#     (at tol = 1e-4: 1e-4 of the element itself plus 5e-6 of the tensor's scale -- the absolute term is what a dot
+#     product of K terms that CANCELS to a small value is entitled to: its rounding noise scales with sum |a_k b_k|,
+#     not with the result.  Round 1 only had the per-tensor check, under which an entry 100x below the maximum could
+#     be 1e-2 off.)
 RTOL = 1e-4
+ATOL_FRAC = 0.05
+ATOL_FLOOR = 5e-7  # relative to max|ref|: comparisons at tol ~1e-6 between two GPU paths still allow summation-order noise
 
 
 def golden(group):
@@ -30,9 +37,25 @@ def rel_err(got, ref):
     return (got - ref).abs().max().item() / max(scale, 1e-30)
 
 
-def assert_close(got, ref, tol=RTOL, what=""):
+def elementwise_excess(got, ref, tol):
+    """max_i |d_i| / (tol |ref_i| + max(ATOL_FRAC tol, ATOL_FLOOR) max|ref|): <= 1 passes."""
+    got = torch.as_tensor(got, dtype=torch.float64).cpu()
+    ref = torch.as_tensor(ref, dtype=torch.float64).cpu()
+    if ref.numel() == 0:
+        return 0.0
+    scale = max(ref.abs().max().item(), 1e-30)
+    bound = tol * ref.abs() + max(ATOL_FRAC * tol, ATOL_FLOOR) * scale
+    return ((got - ref).abs() / bound).max().item()
+
+
+def assert_close(got, ref, tol=RTOL, what="", elementwise=True):
+    """elementwise=False (per-tensor bar only) is for the opt-in bf16x2 GEMM mode alone: ~5e-6 per product by design."""
     e = rel_err(got, ref)
     assert e <= tol, f"{what}: max|d|/max|ref| = {e:.3e} > {tol:.1e}"
+    if not elementwise:
+        return e
+    x = elementwise_excess(got, ref, tol)
+    assert x <= 1.0, f"{what}: elementwise |d| exceeds {tol:.1e}*|ref| + {max(ATOL_FRAC * tol, ATOL_FLOOR):.1e}*max|ref| by {x:.2f}x"
     return e
 
 

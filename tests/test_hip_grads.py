@@ -125,6 +125,55 @@ def test_masked_mean_grad():
     H.assert_close(xd.grad, xo.grad, GTOL)
 
 
+@pytest.mark.parametrize("act", ["tanh", "identity"])
+def test_head_activation_other_than_relu(act):
+    """TextEncoder(activation=...) (news_encoding.py:10-18,27-31): nn.Tanh and nn.Identity heads, forward and gradients
+    against torch autograd of the same stack on the CPU; any other activation module is refused at construction."""
+    import torch.nn as nn
+    mk = {"tanh": nn.Tanh, "identity": nn.Identity}[act]
+    S, D, E = 7, 20, 12
+    enc, sd = load(news_encoding.TextEncoder(pooler=layers.AdditiveAttention(D, 24), p_dropout=0.0, out_features=E, in_features=D,
+                                             head=True, activation=mk(), att=None, bias=True), 47)
+    rng = synth.rng_for(48)
+    x, m = synth.token_block(rng, 2, 3, S, D, min_len=1)
+    xd = x.to(DEV).requires_grad_(True)
+    y, _ = enc((xd, m.to(DEV)))
+    y.pow(2).sum().backward()
+    osd = oracle_sd(sd)
+    xo = x.clone().requires_grad_(True)
+    pooled = O.additive_attention(xo.reshape(6, S, D), m.reshape(6, S, 1), {k[7:]: v for k, v in osd.items() if k.startswith("pooler.")})
+    hmid = mk()(torch.nn.functional.linear(pooled.reshape(6, D), osd["head.0.weight"], osd["head.0.bias"]))
+    yo = torch.nn.functional.linear(hmid, osd["head.2.weight"], osd["head.2.bias"]).reshape(2, 3, E)
+    yo.pow(2).sum().backward()
+    H.assert_close(y, yo, what="forward")
+    H.assert_close(xd.grad, xo.grad, GTOL, "dx")
+    assert check_param_grads(enc, osd) == 8
+    with pytest.raises(NotImplementedError):
+        news_encoding.TextEncoder(pooler=layers.MaskedMean(), p_dropout=0.0, out_features=E, in_features=D, head=True,
+                                  activation=nn.GELU())
+
+
+@pytest.mark.parametrize("normalize", [False, True])
+def test_dot_scoring_grads(normalize):
+    """DotScoring (scoring.py:12-23), both settings of `normalize`, against torch autograd of the reference formula:
+    value, d/du and d/dc; E not a multiple of the wave width, more candidates than waves."""
+    from xnrs_amd.models.components import scoring
+    rng = synth.rng_for(46)
+    u = torch.from_numpy(rng.standard_normal((3, 1, 50)).astype("float32"))
+    c = torch.from_numpy(rng.standard_normal((3, 7, 50)).astype("float32"))
+    w = torch.from_numpy(rng.standard_normal((3, 7, 1)).astype("float32"))
+    ud, cd = u.to(DEV).requires_grad_(True), c.to(DEV).requires_grad_(True)
+    r = scoring.DotScoring(normalize=normalize)(ud, cd)
+    (r * w.to(DEV)).sum().backward()
+    uo, co = u.clone().requires_grad_(True), c.clone().requires_grad_(True)
+    un, cn = (uo / uo.norm(p=2, dim=2, keepdim=True), co / co.norm(p=2, dim=2, keepdim=True)) if normalize else (uo, co)
+    ro = torch.bmm(cn, un.transpose(-1, -2))
+    (ro * w).sum().backward()
+    H.assert_close(r, ro, what="scores")
+    H.assert_close(ud.grad, uo.grad, GTOL, "du")
+    H.assert_close(cd.grad, co.grad, GTOL, "dc")
+
+
 @pytest.mark.parametrize("name", ["standard_bias", "standard_tiny", "base_tiny", "nrms_300", "naml_tiny"])
 def test_model_grads_vs_oracle(name):
     c = cases.MODELS[name]

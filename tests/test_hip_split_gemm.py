@@ -117,7 +117,7 @@ def test_gather_rows_under_split(split_mode):
             y1, hm1 = enc.forward_ids(tx, tm, ids)   # 64-bit row pointers (pointer variant of the kernel)
             y2, hm2 = enc((tx[ids], tm[ids]))         # buffer-load variant
             assert torch.equal(y1, y2) and torch.equal(hm1, hm2)
-            H.assert_close(y1, y0, tol=1e-5 if mode == 1 else 1e-4, what=f"mode {mode} vs fp32 MFMA")
+            H.assert_close(y1, y0, tol=1e-5 if mode == 1 else 1e-4, what=f"mode {mode} vs fp32 MFMA", elementwise=mode == 1)
 
 
 @pytest.mark.parametrize("mode", [1, 2])
@@ -134,12 +134,14 @@ def test_golden_models_under_split(split_mode, mode, name):
     split_mode(mode)
     with torch.no_grad():
         if c["model"] == "NAML":
-            H.assert_close(model(batch), g[f"{name}/r"], what=name)
+            H.assert_close(model(batch), g[f"{name}/r"], what=name, elementwise=mode == 1)
             return
         r, u, cc = model(batch, return_embeddings=True)
-    H.assert_close(r, g[f"{name}/r"], what=name + " scores")
-    H.assert_close(u, g[f"{name}/u"], what=name + " user")
-    H.assert_close(cc, g[f"{name}/c"], what=name + " cand")
+    # bf16x3 (mode 1) is held to the full bar, elementwise included; bf16x2 (mode 2, ~5e-6 per product by design) to the
+    # per-tensor bar
+    H.assert_close(r, g[f"{name}/r"], what=name + " scores", elementwise=mode == 1)
+    H.assert_close(u, g[f"{name}/u"], what=name + " user", elementwise=mode == 1)
+    H.assert_close(cc, g[f"{name}/c"], what=name + " cand", elementwise=mode == 1)
 
 
 def test_benchmark_shape_scores_under_split(split_mode):
@@ -158,8 +160,9 @@ def test_benchmark_shape_scores_under_split(split_mode):
         r1 = bench.step(model, hist, cand)
         split_mode(2)
         r2 = bench.step(model, hist, cand)
-    H.assert_close(r1, r0, tol=5e-6, what="bf16x3 vs fp32 MFMA")
-    H.assert_close(r2, r0, tol=1e-4, what="bf16x2 vs fp32 MFMA")
+    H.assert_close(r1, r0, tol=5e-6, what="bf16x3 vs fp32 MFMA", elementwise=False)
+    H.assert_close(r1, r0, tol=2e-5, what="bf16x3 vs fp32 MFMA (elementwise: 2e-5 |ref| + 1e-6 max|ref|)")
+    H.assert_close(r2, r0, tol=1e-4, what="bf16x2 vs fp32 MFMA", elementwise=False)
 
 
 @pytest.mark.parametrize("mode", [1, 2])

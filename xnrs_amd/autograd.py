@@ -43,6 +43,7 @@ class _Cfg:
         self.has_head, self.E, self.head_bias = has_head, E, head_bias
         self.dropout_p, self.seed = dropout_p, seed
         self.want_a = want_a
+        self.head_act = hip.ACT_RELU
 
 
 def _param_structs(cfg: _Cfg, params: List[Optional[torch.Tensor]]):
@@ -63,7 +64,7 @@ def _param_structs(cfg: _Cfg, params: List[Optional[torch.Tensor]]):
         i += 4
     if cfg.has_head:
         ts = [None if t is None else hip.dev_f32(t, "head weight") for t in params[i:i + 4]]
-        hp = hip.HeadParams(*[None if t is None else t.data_ptr() for t in ts], cfg.E)
+        hp = hip.HeadParams(*[None if t is None else t.data_ptr() for t in ts], cfg.E, cfg.head_act)
         keep += ts
         i += 4
     return ap, pp, hp, keep
@@ -183,6 +184,8 @@ def _run(x, m, ids, att, pooler, head, pool_kind, dropout_p, seed, want_a):
         params += _head_tensors(head)
         has_head, E = True, head[0].out_features
     cfg = _Cfg(n, L, D, n_heads, scaled, pool_kind, A, has_head, E, head_bias, dropout_p, seed, want_a)
+    if head is not None:
+        cfg.head_act = hip.head_activation(head[1])
     y, a, hm = _SeqEncode.apply(cfg, x, m2, ids, *params)
     return y, (a if a.numel() else None), (hm if hm.numel() else None)
 
@@ -300,13 +303,14 @@ def embedding_linear(idx, embedder, fc):
 
 class _DotScoring(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, u, c):
+    def forward(ctx, u, c, normalize):
         from . import ops
         u = hip.dev_f32(u, "user vector")
         c = hip.dev_f32(c, "candidate vectors")
         ctx.save_for_backward(u, c)
+        ctx.normalize = bool(normalize)
         with torch.no_grad():
-            return ops.dot_scoring_forward(u, c, False)
+            return ops.dot_scoring_forward(u, c, ctx.normalize)
 
     @staticmethod
     def backward(ctx, dr):
@@ -315,13 +319,11 @@ class _DotScoring(torch.autograd.Function):
         B, Cn, E = c.shape
         du = torch.empty_like(u) if ctx.needs_input_grad[0] else None
         dc = torch.empty_like(c) if ctx.needs_input_grad[1] else None
-        hip.check(hip.lib().xnrs_dot_scoring_bwd(hip.ptr(u), hip.ptr(c), hip.ptr(dr), hip.ptr(du), hip.ptr(dc), B, Cn, E,
-                                                 hip.stream_ptr(c.device)), "xnrs_dot_scoring_bwd")
-        return du, dc
+        fn = hip.lib().xnrs_dot_scoring_norm_bwd if ctx.normalize else hip.lib().xnrs_dot_scoring_bwd
+        hip.check(fn(hip.ptr(u), hip.ptr(c), hip.ptr(dr), hip.ptr(du), hip.ptr(dc), B, Cn, E, hip.stream_ptr(c.device)),
+                  "xnrs_dot_scoring_norm_bwd" if ctx.normalize else "xnrs_dot_scoring_bwd")
+        return du, dc, None
 
 
 def dot_scoring(u, c, normalize):
-    if normalize:
-        raise NotImplementedError("backward of DotScoring(normalize=True) is not built (the reference's "
-                                  "make_model never enables it, make_model.py:22)")
-    return _DotScoring.apply(u, c)
+    return _DotScoring.apply(u, c, normalize)

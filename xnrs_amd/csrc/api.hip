@@ -167,7 +167,8 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
     if (additive && (!pool || !pool->w1 || !pool->w2 || pool->hidden <= 0)) return XNRS_EINVAL;
     if (pool_kind == XNRS_POOL_MEAN && !m) return XNRS_EINVAL;
     if (L > 512) return XNRS_EUNSUPPORTED;
-    if (head && (!head->w0 || !head->w2 || head->out_features <= 0)) return XNRS_EINVAL;
+    if (head && (!head->w0 || !head->w2 || head->out_features <= 0 || head->activation < 0 || head->activation > 2))
+      return XNRS_EINVAL;
   }
   if (ids && !m && pooled && pool_kind == XNRS_POOL_MEAN) return XNRS_EINVAL;
   const int A = additive ? pool->hidden : 0;
@@ -351,7 +352,7 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
   }
   if (pooled && head) {
     ProfScope ps(5, 2.0 * n_seq * ((double)D * E + (double)E * E), stream);
-    XNRS_TRY(launch_gemm_f32(gemm1(pb, nullptr, 0, D, head->w0, head->b0, hb, E, n_seq, E, D, XNRS_ACT_RELU), stream));
+    XNRS_TRY(launch_gemm_f32(gemm1(pb, nullptr, 0, D, head->w0, head->b0, hb, E, n_seq, E, D, head->activation), stream));
     XNRS_TRY(launch_gemm_f32(gemm1(hb, nullptr, 0, E, head->w2, head->b2, y, E, n_seq, E, E, XNRS_ACT_NONE), stream));
   }
   return XNRS_OK;
@@ -565,7 +566,7 @@ int32_t xnrs_text_encoder_fwd_unpadded(const float* x, const int32_t* ids, int64
   }
   if (head) {
     ProfScope ps(5, 2.0 * n_news * ((double)D * E + (double)E * E), stream);
-    XNRS_TRY(launch_gemm_f32(gemm1(pb, nullptr, 0, D, head->w0, head->b0, hb, E, n_news, E, D, XNRS_ACT_RELU), stream));
+    XNRS_TRY(launch_gemm_f32(gemm1(pb, nullptr, 0, D, head->w0, head->b0, hb, E, n_news, E, D, head->activation), stream));
     XNRS_TRY(launch_gemm_f32(gemm1(hb, nullptr, 0, E, head->w2, head->b2, y, E, n_news, E, E, XNRS_ACT_NONE), stream));
   }
   return XNRS_OK;
@@ -867,7 +868,9 @@ int32_t xnrs_seq_encoder_bwd_live(const float* x, const float* m, const int32_t*
     if (head) {
       if (g_head && g_head->w2) XNRS_TRY(gemm_dw(dy, E, hb, nullptr, 0, E, g_head->w2, n_seq, E, E, slabs, stream));
       if (g_head && g_head->b2) XNRS_TRY(launch_colsum(dy, E, nullptr, n_seq, E, g_head->b2, csum, stream));
-      XNRS_TRY(gemm_dx(dy, E, head->w2, dh, E, n_seq, E, E, hb, E, /*relu'*/ 2, 0, stream, wt));
+      // f'(saved activation): relu' (aux mode 2), tanh' = 1 - t^2 (1), identity (0)
+      const int hmode = head->activation == XNRS_ACT_RELU ? 2 : (head->activation == XNRS_ACT_TANH ? 1 : 0);
+      XNRS_TRY(gemm_dx(dy, E, head->w2, dh, E, n_seq, E, E, hmode ? hb : nullptr, E, hmode, 0, stream, wt));
       if (g_head && g_head->w0) XNRS_TRY(gemm_dw(dh, E, pb, nullptr, 0, D, g_head->w0, n_seq, E, D, slabs, stream));
       if (g_head && g_head->b0) XNRS_TRY(launch_colsum(dh, E, nullptr, n_seq, E, g_head->b0, csum, stream));
       XNRS_TRY(gemm_dx(dh, E, head->w0, dp, D, n_seq, E, D, nullptr, 0, 0, 0, stream, wt));
@@ -1009,6 +1012,13 @@ int32_t xnrs_dot_scoring_bwd(const float* u, const float* c, const float* dr, fl
                              int32_t E, void* stream) {
   if (!u || !c || !dr || B < 0 || C <= 0 || E <= 0) return XNRS_EINVAL;
   return hip_rc(launch_dot_scoring_bwd(u, c, dr, du, dc, B, C, E, (hipStream_t)stream));
+}
+
+int32_t xnrs_dot_scoring_norm_bwd(const float* u, const float* c, const float* dr, float* du, float* dc, int64_t B, int32_t C,
+                                  int32_t E, void* stream) {
+  if (!u || !c || !dr || B < 0 || C <= 0 || E <= 0) return XNRS_EINVAL;
+  if (E > 1024) return XNRS_EUNSUPPORTED;
+  return hip_rc(launch_dot_scoring_norm_bwd(u, c, dr, du, dc, B, C, E, (hipStream_t)stream));
 }
 
 }  // extern "C"

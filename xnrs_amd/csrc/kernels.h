@@ -252,6 +252,8 @@ hipError_t launch_colsum(const float* X, int64_t ldx, const float* w, int64_t M,
                          hipStream_t stream);
 hipError_t launch_dot_scoring_bwd(const float* u, const float* c, const float* dr, float* du, float* dc, int64_t B, int32_t C,
                                   int32_t E, hipStream_t stream);
+hipError_t launch_dot_scoring_norm_bwd(const float* u, const float* c, const float* dr, float* du, float* dc, int64_t B,
+                                       int32_t C, int32_t E, hipStream_t stream);
 
 hipError_t launch_embedding_grad(const float* d_rows, const int32_t* ids, int64_t M, int K, float* d_table, int n_rows,
                                  hipStream_t stream);

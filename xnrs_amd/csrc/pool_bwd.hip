@@ -3,7 +3,7 @@
 //   additive_pool_bwd : autograd of layers.AdditiveAttention.forward after fc1+tanh (layers.py:60-65)
 //   mean_pool_bwd     : autograd of layers.MaskedMean.forward (layers.py:35-36)
 //   colsum            : out[n] = sum_m w[m] * X[m][n]  (bias grads: w == NULL; fc2.weight grad: X = tanh(fc1 x), w = de)
-//   dot_scoring_bwd   : autograd of DotScoring.forward, normalize=False (scoring.py:23)
+//   dot_scoring_bwd   : autograd of DotScoring.forward (scoring.py:20-23), plain and L2-normalised
 #include "kernels.h"
 
 namespace xnrs {
@@ -170,6 +170,54 @@ __global__ __launch_bounds__(256) void dot_scoring_bwd_kernel(const float* u, co
     if (dc) dc[(b * C + k) * E + e] = g * uv;
   }
   if (du) du[i] = acc;
+}
+
+// normalize=True (scoring.py:20-22): r_k = <c_k, u> / (|c_k| |u|).  With uh = u/|u|, ch = c_k/|c_k|:
+//   dr_k/du = (ch - r_k uh) / |u| ,  dr_k/dc_k = (uh - r_k ch) / |c_k|
+// one workgroup per impression; wave w takes candidates w, w+4, ...; per-wave partial du rows summed in a fixed order
+constexpr int DOTN_MAX_E = 1024;
+__global__ __launch_bounds__(256) void dot_scoring_norm_bwd_kernel(const float* u, const float* c, const float* dr, float* du,
+                                                                    float* dc, int C, int E) {
+  __shared__ float s_du[4][DOTN_MAX_E];
+  const int64_t b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* ub = u + b * E;
+  float nu2 = 0.f;
+  for (int e = lane; e < E; e += 64) {
+    nu2 = fmaf(ub[e], ub[e], nu2);
+    s_du[wave][e] = 0.f;
+  }
+  nu2 = wave_sum_b(nu2);
+  const float inv_u = 1.f / sqrtf(nu2);
+  for (int k = wave; k < C; k += 4) {
+    const float* ck = c + (b * C + k) * E;
+    float nc2 = 0.f, dot = 0.f;
+    for (int e = lane; e < E; e += 64) {
+      nc2 = fmaf(ck[e], ck[e], nc2);
+      dot = fmaf(ck[e], ub[e], dot);
+    }
+    nc2 = wave_sum_b(nc2);
+    dot = wave_sum_b(dot);
+    const float inv_c = 1.f / sqrtf(nc2);
+    const float r = dot * inv_u * inv_c;
+    const float g = dr[b * C + k];
+    for (int e = lane; e < E; e += 64) {
+      const float uh = ub[e] * inv_u, ch = ck[e] * inv_c;
+      if (dc) dc[(b * C + k) * E + e] = g * (uh - r * ch) * inv_c;
+      s_du[wave][e] += g * (ch - r * uh) * inv_u;
+    }
+  }
+  __syncthreads();
+  if (du)
+    for (int e = threadIdx.x; e < E; e += 256) du[b * E + e] = (s_du[0][e] + s_du[1][e]) + (s_du[2][e] + s_du[3][e]);
+}
+
+hipError_t launch_dot_scoring_norm_bwd(const float* u, const float* c, const float* dr, float* du, float* dc, int64_t B,
+                                       int32_t C, int32_t E, hipStream_t stream) {
+  if (B <= 0) return hipSuccess;
+  if (E > DOTN_MAX_E || B > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(dot_scoring_norm_bwd_kernel, dim3((unsigned)B), dim3(256), 0, stream, u, c, dr, du, dc, C, E);
+  return hipGetLastError();
 }
 
 hipError_t launch_dot_scoring_bwd(const float* u, const float* c, const float* dr, float* du, float* dc, int64_t B, int32_t C,

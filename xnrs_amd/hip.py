@@ -28,7 +28,7 @@ SYMBOLS = (
     "xnrs_text_encoder_unpadded_workspace_bytes", "xnrs_text_encoder_fwd_unpadded",
     "xnrs_seq_encoder_saved_bytes", "xnrs_seq_encoder_fwd_train", "xnrs_seq_encoder_bwd_workspace_bytes",
     "xnrs_seq_encoder_bwd", "xnrs_seq_encoder_bwd_live", "xnrs_linear_bwd_workspace_bytes", "xnrs_linear_bwd",
-    "xnrs_embedding_linear_bwd_workspace_bytes", "xnrs_embedding_linear_bwd", "xnrs_dot_scoring_bwd",
+    "xnrs_embedding_linear_bwd_workspace_bytes", "xnrs_embedding_linear_bwd", "xnrs_dot_scoring_bwd", "xnrs_dot_scoring_norm_bwd",
     "xnrs_assemble_train_batch", "xnrs_assemble_eval_batch", "xnrs_score_csr", "xnrs_rank_metrics", "xnrs_gather_rows",
     "xnrs_infonce_saved_bytes", "xnrs_infonce_fwd", "xnrs_infonce_bwd",
 )
@@ -50,7 +50,7 @@ class AdditiveParams(C.Structure):
 
 
 class HeadParams(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("w0", "b0", "w2", "b2")] + [("out_features", C.c_int32)]
+    _fields_ = [(n, C.c_void_p) for n in ("w0", "b0", "w2", "b2")] + [("out_features", C.c_int32), ("activation", C.c_int32)]
 
 
 class MhaGrads(C.Structure):
@@ -139,6 +139,8 @@ def lib():
     l.xnrs_embedding_linear_bwd.argtypes = [p, p, p, p, p, p, p, i64, i32, i32, i32, p, sz, p]
     l.xnrs_dot_scoring_bwd.restype = i32
     l.xnrs_dot_scoring_bwd.argtypes = [p, p, p, p, p, i64, i32, i32, p]
+    l.xnrs_dot_scoring_norm_bwd.restype = i32
+    l.xnrs_dot_scoring_norm_bwd.argtypes = [p, p, p, p, p, i64, i32, i32, p]
     l.xnrs_assemble_train_batch.restype = i32
     l.xnrs_assemble_train_batch.argtypes = [p, i64, p, p, p, p, p, p, i32, i32, i32, C.c_uint64, p, p, p]
     l.xnrs_assemble_eval_batch.restype = i32
@@ -165,7 +167,7 @@ def lib():
     l.xnrs_profile_enable.argtypes = [C.c_uint32]
     l.xnrs_profile_read.restype = i32
     l.xnrs_profile_read.argtypes = [p, p, p]
-    if l.xnrs_abi_version() != 1:
+    if l.xnrs_abi_version() != 2:
         raise XnrsHipError("libxnrs_hip.so ABI version mismatch; rebuild it")
     _lib = l
     return l
@@ -300,4 +302,18 @@ def head_params(head):
     l0, l2 = head[0], head[2]
     ts = [dev_f32(l0.weight, "head.0.weight"), None if l0.bias is None else dev_f32(l0.bias, "head.0.bias"),
           dev_f32(l2.weight, "head.2.weight"), None if l2.bias is None else dev_f32(l2.bias, "head.2.bias")]
-    return HeadParams(*[None if t is None else t.data_ptr() for t in ts], l0.out_features), ts
+    return HeadParams(*[None if t is None else t.data_ptr() for t in ts], l0.out_features, head_activation(head[1])), ts
+
+
+def head_activation(mod) -> int:
+    """The head's activation module -> epilogue code.  nn.ReLU (the reference default, news_encoding.py:18),
+    nn.Tanh and nn.Identity are what the GEMM epilogue and its backward implement; anything else is refused."""
+    import torch.nn as nn
+    if isinstance(mod, nn.ReLU):
+        return ACT_RELU
+    if isinstance(mod, nn.Tanh):
+        return ACT_TANH
+    if isinstance(mod, nn.Identity):
+        return ACT_NONE
+    raise NotImplementedError(f"head activation {type(mod).__name__}: the HIP head implements nn.ReLU (reference default), "
+                              "nn.Tanh and nn.Identity")

@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import hip, ops
 
 
 # ------------------------------------------------------------------------------------------- poolers / attention
@@ -54,8 +54,7 @@ class MultiHeadAttention(nn.Module):
 
 # ------------------------------------------------------------------------------------------- encoders
 def _mlp_head(n_in: int, n_out: int, activation: nn.Module, bias: bool) -> nn.Sequential:
-    if not isinstance(activation, nn.ReLU):
-        raise NotImplementedError("the HIP head kernel implements the reference default ReLU only")
+    hip.head_activation(activation)  # nn.ReLU (reference default), nn.Tanh, nn.Identity; anything else raises here
     return nn.Sequential(nn.Linear(n_in, n_out, bias=bias), activation, nn.Linear(n_out, n_out, bias=bias))
 
 
@@ -133,6 +132,12 @@ class TextEncoder(_Tower):
     def forward_ids(self, table_x: torch.Tensor, table_m: torch.Tensor, ids: torch.Tensor, dedup: bool = False):
         """dedup=True encodes every distinct row once and scatters the vectors back (SURVEY.md section 8f rank 1:
         "unique-news dedup per step"); it changes the algorithmic work, so benchmarks report it separately."""
+        if self.training and self.dropout.p > 0:
+            # forward() applies the input dropout (news_encoding.py:51); a gathered table row cannot be dropped out
+            # in the GEMM load, so training through the id path with p_dropout > 0 would silently train another model
+            raise hip.XnrsHipError("TextEncoder.forward_ids: input dropout (p_dropout > 0) is not applied on the id-gather "
+                                   "path; train with p_dropout = 0 (every shipped config) or through forward() on "
+                                   "NewsStore.gather(ids)")
         b, n = ids.shape
         flat = ids.reshape(-1)
         encode = self._encoder_fn()
