@@ -84,13 +84,18 @@ def build_model(w, device, seed=1234, model_name="NRMS"):
     return model.eval().to(device), sd
 
 
-def make_inputs(w, device, seed):
+def make_inputs(w, device, seed, full_history=False):
+    """SURVEY.md section 8d inputs: token length ~ U{5..S}, history length ~ U{1..H} (trailing slots all-zero).
+    full_history=True keeps every history slot live (no all-zero news rows: the GEMM then multiplies random data
+    everywhere -- the DVFS-honest variant of the same step)."""
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     B, H, C, S, D = w["B"], w["H"], w["C"], w["S"], w["D"]
     hx, hm = synth.device_tokens(gen, B * H, S, D, device)
     # ragged histories: trailing slots of each impression are empty (all-zero x and m, dataset.py:82-85)
     n_hist = torch.randint(1, H + 1, (B, 1), generator=gen, device=device)
+    if full_history:
+        n_hist = torch.full_like(n_hist, H)
     slot_valid = (torch.arange(H, device=device)[None, :] < n_hist).reshape(B * H, 1, 1).to(torch.float32)
     hx.mul_(slot_valid)
     hm.mul_(slot_valid)
@@ -202,24 +207,45 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(w, sd, sample_B=32, reps=3):
-    """Oracle (torch CPU fp32 restatement, pinned to the reference by tests/golden) on the host cores."""
+def cpu_baseline(w, sd, sample_B=32, reps=10, warm=3, one_thread_B=4, one_thread_reps=3):
+    """Oracle (torch CPU fp32 restatement, pinned to the reference by tests/golden) on the host cores: `warm` warm-up
+    passes + `reps` timed passes over a `sample_B`-impression sample of the same workload shape with every usable core
+    (BASELINE.md section 3), and a 1-thread line on a smaller sample (it is ~cores x slower)."""
     from oracle import xnrs_oracle as O
     threads = usable_cores()
-    torch.set_num_threads(threads)
     rng_batch = synth.make_batch(77, sample_B, w["H"], w["C"], w["S"], w["D"], min_len=5)
     hist = rng_batch["user_features"]["history"]["title_emb"]
     cand = rng_batch["candidate_features"]["title_emb"]
     sdc = {k: v.float().cpu() for k, v in sd.items()}
-    with torch.no_grad():
-        O.parent_forward(hist, cand, sdc, w["h"])  # warm-up
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            r = O.parent_forward(hist, cand, sdc, w["h"])
-        dt = (time.perf_counter() - t0) / reps
-    return dict(value=sample_B / dt, unit="impressions/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{sample_B} impressions of the same workload shape (H={w['H']},C={w['C']},S={w['S']},D={w['D']}), "
-                       f"{reps} timed passes after 1 warm-up, {dt:.2f} s/pass"), r
+
+    def run(h, c, n_warm, n_rep):
+        with torch.no_grad():
+            for _ in range(n_warm):
+                r = O.parent_forward(h, c, sdc, w["h"])
+            t0 = time.perf_counter()
+            for _ in range(n_rep):
+                r = O.parent_forward(h, c, sdc, w["h"])
+            return (time.perf_counter() - t0) / n_rep, r
+
+    torch.set_num_threads(threads)
+    dt, r = run(hist, cand, warm, reps)
+    used = torch.get_num_threads()
+    torch.set_num_threads(1)
+    k = one_thread_B
+    dt1, _ = run((hist[0][:k], hist[1][:k]), (cand[0][:k], cand[1][:k]), 1, one_thread_reps)
+    torch.set_num_threads(threads)
+    cpu = ""
+    try:
+        cpu = next(ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
+    shape = f"(H={w['H']},C={w['C']},S={w['S']},D={w['D']})"
+    return dict(value=sample_B / dt, unit="impressions/s", cores=used, kind="port",
+                sample=f"{sample_B} impressions of the same workload shape {shape}, {reps} timed passes after {warm} warm-ups, "
+                       f"{dt:.2f} s/pass",
+                one_thread=dict(value=k / dt1, unit="impressions/s", cores=1,
+                                sample=f"{k} impressions {shape}, {one_thread_reps} timed passes after 1 warm-up, {dt1:.2f} s/pass"),
+                cpu_model=cpu, logical_cpus=os.cpu_count()), r
 
 
 def news_only_extra(device, steps=20, warmup=10):
@@ -378,6 +404,55 @@ def eval_epoch_extra(device, n_news=20000, n_sess=20000):
     return dict(n_news=n_news, n_impressions=n_sess, candidates=int(beh.pos_off[-1] + beh.neg_off[-1]), seconds=dt,
                 impressions_per_s=n_sess / dt, auc=res["auc"],
                 unpadded=dict(seconds=dt_u, impressions_per_s=n_sess / dt_u, same_metrics=bool(res_u == res)))
+
+
+def gather_roofline(device, n_news=16384, n=512 * 55, reps=5):
+    """The gather stage as its own kernel (xnrs_gather_rows: out[i] = table[ids[i]] for whole 150-KB news blocks, what
+    NewsRecDataset.__getitem__ + torch.cat do on the host): HBM-bound, timed live with events on the launching stream.
+    Algorithmic bytes = rows read + rows written.  The counter view (FETCH_SIZE x2 / WRITE_SIZE) of the same kernel on the
+    65 536-news table is profiles/r02_gather_rocprof.txt; inside the encoders the gather is folded into the first GEMM's
+    loads instead (extra.id_path_B512)."""
+    import numpy as np
+    from xnrs_amd.data import NewsStore
+    w = WORKLOAD
+    gen = torch.Generator(device=device)
+    gen.manual_seed(31)
+    tx, tm = synth.device_tokens(gen, n_news + 1, w["S"], w["D"], device)
+    store = NewsStore(tx, tm.reshape(n_news + 1, w["S"]), list(range(n_news)))
+    rng = np.random.default_rng(5)
+    out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "gather_rows_kernel<true>",
+           "table": f"{n_news} news x {w['S']} x {w['D']} fp32 ({(n_news + 1) * w['S'] * w['D'] * 4 / 1e9:.1f} GB)", "rows": n}
+    row_bytes = w["S"] * w["D"] * 4
+    for dist in ("uniform", "zipf1.1"):
+        ids = rng.integers(1, n_news + 1, size=n) if dist == "uniform" else np.minimum(rng.zipf(1.1, size=n), n_news)
+        ids = torch.from_numpy(ids.astype(np.int32)).to(device)
+        x = torch.empty((n, w["S"], w["D"]), dtype=torch.float32, device=device)
+        st = hip.stream_ptr(device)
+
+        def go():
+            hip.check(hip.lib().xnrs_gather_rows(hip.ptr(store.x), hip.ptr(ids), hip.ptr(x), n, w["S"] * w["D"], st), "xnrs_gather_rows")
+        go()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            go()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        gbs = 2.0 * n * row_bytes / (ms * 1e-3) / 1e9
+        out[dist] = {"achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "avg_launch_ms": ms, "alg_bytes_per_launch": 2 * n * row_bytes,
+                     "distinct_rows": int(torch.unique(ids).numel())}
+        del x
+    out["achieved"], out["frac"] = out["uniform"]["achieved"], out["uniform"]["frac"]
+    out["traffic"] = None
+    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        out["traffic"] = tj.get("gather_rows_hbm_bytes_per_launch")
+        out["traffic_source"] = {"file": "profiles/r02_traffic.json", "commit": tj.get("commit"), "date": tj.get("date"),
+                                 "note": tj.get("gather_note")}
+    return out
 
 
 def id_path_extra(device, steps=5, warmup=2, n_news=65536):
@@ -628,10 +703,17 @@ def main():
     if rank == 0:
         q_ms, q_n, q_fl = prof["qkv_gemm"]
         ach = (q_fl / max(q_n, 1)) / (q_ms / max(q_n, 1) * 1e-3) / 1e12 if q_n else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("qkv_gemm_hbm_bytes_per_launch")
+        # `traffic` cannot be measured in this run (PMC counters need rocprofv3 around the process): it is read from the
+        # committed PMC summary of the SAME kernel and launch shape and labelled with where and when that was taken
+        traffic, traffic_source = None, None
+        for tname in ("r02_traffic.json", "r01_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                traffic = tj.get("qkv_gemm_hbm_bytes_per_launch")
+                traffic_source = {"file": "profiles/" + tname, "commit": tj.get("commit"), "date": tj.get("date"),
+                                  "kernel": tj.get("kernel"), "method": tj.get("method", "rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE, separate passes")}
+                break
         out = {
             "metric": "impressions/sec (encode+score) on MIND-shaped batches",
             "value": value,
@@ -658,6 +740,8 @@ def main():
                          "unit": "TFLOP/s",
                          "frac": ach * mode_products / (FP32_MFMA_PEAK_TFLOPS if args.gemm_mode == 0 else BF16_MFMA_PEAK_TFLOPS),
                          "traffic": traffic if args.gemm_mode == 0 else None,
+                         "traffic_source": traffic_source if args.gemm_mode == 0 else None,
+                         "alg_bytes_per_launch": (q_fl / max(q_n, 1)) / (6.0 * w["D"] * w["D"]) * (4 * w["D"] + 12 * w["D"]),
                          "kernel": ("gemm_f32_kernel<2,2,...> (fused Q/K/V projection)" if args.gemm_mode == 0 else
                                     f"gemm_split_kernel<{4 - args.gemm_mode},...> (fused Q/K/V projection)"),
                          "alg_tflops": ach,
@@ -668,6 +752,28 @@ def main():
                            "alg_gbs": impression_bytes(w) * value / n_gpus / 1e9,
                            "frac_hbm": impression_bytes(w) * value / n_gpus / 1e9 / HBM_PEAK_GBS},
         }
+        if n_gpus == 1:
+            # the same step on a batch with EVERY history slot live: no all-zero news rows anywhere, so the dominant GEMM
+            # multiplies random data throughout (the section-8d batch above has ~45 % all-zero rows, on which the chip
+            # holds a higher clock); a few steps, same live hipEvent timing
+            with torch.no_grad():
+                hist_f, cand_f = make_inputs(w, device, seed=4000, full_history=True)
+                fn_f = lambda: step(model, hist_f, cand_f)  # noqa: E731
+                for _ in range(2):
+                    fn_f()
+                hip.profile_enable(1)
+                dt_f = timed(fn_f, max(3, args.steps // 2), 0, False)
+                pf = hip.profile_read()
+                hip.profile_enable(0)
+                del hist_f, cand_f
+            f_ms, f_n, f_fl = pf["qkv_gemm"]
+            ach_f = (f_fl / f_ms * 1e3 / 1e12) if f_ms > 0 else 0.0
+            out["roofline"]["fully_live_random_batch"] = {
+                "achieved": ach_f * mode_products, "frac": ach_f * mode_products / out["roofline"]["peak"],
+                "avg_launch_ms": f_ms / max(f_n, 1), "launches_timed": f_n,
+                "impressions_per_s": w["B"] * max(3, args.steps // 2) / dt_f,
+                "note": "same step, every history slot live (no all-zero news rows)"}
+            out["roofline_gather"] = gather_roofline(device)
         cpu_sample = None
         if n_gpus == 1 and not args.no_cpu_baseline:
             cb, ref = cpu_baseline(w, sd)

@@ -304,13 +304,21 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
   };
   // physical 16-byte chunk of logical chunk c in row `row` of a k-contiguous LDS tile
   auto kswz = [](int row, int c) { return SWZ ? (c ^ ((row >> 2) & 3)) : c; };
-  auto sstore = [&](auto P, int buf, int only = -1) {
+  // fused column sums of a k-major A (bias gradients, GemmArgs::colsum): the first column tile of every row tile adds
+  // up the A chunks it stages -- each staged exactly once per K tile (`fresh`: the pipeline's redundant re-store of the
+  // last tile at the tail must not count twice)
+  const bool do_cs = A_COL && a.colsum != nullptr && nt == 0;
+  f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+  auto sstore = [&](auto P, int buf, int only = -1, bool fresh = true) {
     constexpr int p = decltype(P)::value;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       if (only >= 0 && only != i) continue;
       if (!A_COL) *reinterpret_cast<f32x4*>(&As[buf][(lr + RPP * i) * LDA + 4 * kswz(lr + RPP * i, lc)]) = ra[p][i];
-      else *reinterpret_cast<f32x4*>(&As[buf][(kA + KRA * i) * LDA + 4 * cA]) = ra[p][i];
+      else {
+        *reinterpret_cast<f32x4*>(&As[buf][(kA + KRA * i) * LDA + 4 * cA]) = ra[p][i];
+        if (do_cs && fresh) cs += ra[p][i];
+      }
     }
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
@@ -443,12 +451,31 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
             for (int j = 0; j < TN; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kq & 1][i][e], fb[kq & 1][j][e], acc[i][j], 0, 0, 0);
           if (e == 1 && kq + 1 < NKQ) ldfrag((kq + 1) & 1, buf, kq + 1);
-          if (slot >= 1 && slot < 1 + NCH) sstore(I0{}, buf ^ 1, slot - 1);  // tile t+1 -> LDS (redundant at the tail)
+          if (slot >= 1 && slot < 1 + NCH) sstore(I0{}, buf ^ 1, slot - 1, t < last);  // tile t+1 -> LDS (redundant at the tail)
           if (slot >= 2 && slot < 2 + NCH) gload(I0{}, kn, slot - 2);        // tile t+2 -> the register just stored
           __builtin_amdgcn_sched_barrier(0);
         }
       }
       __syncthreads();
+    }
+  }
+
+  if constexpr (A_COL) {
+    if (a.colsum != nullptr && nt == 0) {  // workgroup-uniform
+      // the KRA threads that staged the same 4 columns (same cA, k rows kA + KRA i) add up through LDS (the K loop's
+      // last barrier has passed: the tile buffers are free)
+      f32x4* red = reinterpret_cast<f32x4*>(&As[0][0]);
+      red[kA * CHA + cA] = cs;
+      __syncthreads();
+      if (kA == 0) {
+        f32x4 v = red[cA];
+#pragma unroll
+        for (int r = 1; r < KRA; ++r) v += red[r * CHA + cA];
+        float* dst = a.colsum + (int64_t)blockIdx.y * a.M + m0 + 4 * cA;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (m0 + 4 * cA + e < a.M) dst[e] = v[e];
+      }
     }
   }
 
@@ -663,7 +690,7 @@ void reload_knobs() { g_knobs = read_knobs(); }
 int gemm_mode() { return g_gemm_mode.load(std::memory_order_relaxed); }
 void set_gemm_mode(int mode) { g_gemm_mode.store((mode >= 0 && mode <= 2) ? mode : 0, std::memory_order_relaxed); }
 
-hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t stream) {
+hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t stream, int* nsplit_used) {
   GemmArgs a = a_in;
   if (a.M <= 0 || a.Nseg <= 0) return hipSuccess;
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
@@ -686,6 +713,8 @@ hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t stream) {
     nsplit = 1;
     a.k_per_split = a.K > 0 ? a.K : 1;
   }
+  if (nsplit_used) *nsplit_used = nsplit;
+  if (a.colsum && !(a.a_col && a.b_kn)) return hipErrorInvalidValue;  // fused column sums: dW layout only
   hipError_t e;
   const int mode = gemm_mode();
   // the split kernel has one tile shape (128x128): below one full round of workgroups the fp32 kernel with its

@@ -67,6 +67,10 @@ struct GemmArgs {
   // instead of splitting the fp32 weights again in every row tile
   const unsigned short* Wp[3];
   int64_t ldp;
+  // k-major A only (dW = dY^T . X): also emit the column sums of A over the contraction, colsum[split][M] partials (the
+  // bias gradient db = sum_rows dY is a by-product of the tiles this kernel stages anyway); nullable.  The caller
+  // reduces the nsplit partial rows (launch_colsum_final).
+  float* colsum;
   // split-K (deterministic slabs + ordered reduce); set by the caller via slabs/nsplit
   float* slabs;        // nullable workspace of nsplit * M * ldc floats
   int32_t nsplit;
@@ -78,7 +82,7 @@ hipError_t launch_transpose(const float* W, float* Wt, int rows, int cols, hipSt
 int gemm_pick_splits(int64_t M, int64_t N, int64_t K);
 int gemm_group_tiles(int n_tiles, int bn, int64_t K, bool plain);
 size_t gemm_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
-hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t stream);
+hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t stream, int* nsplit_used = nullptr);
 // forward-layout GEMM on the bf16 matrix cores by operand splitting (gemm_split.hip); npl = 3 or 2 planes
 hipError_t launch_gemm_split(const GemmArgs& a, int npl, hipStream_t stream);
 // planes[p][k/16][n][16] (p = 0..2: hi, mid, lo; k zero padded to ldp = split_plane_ld(K)) of W[N][K]: the
@@ -250,6 +254,8 @@ hipError_t launch_mean_pool_bwd(const float* dy, const float* mask, const int32_
 size_t colsum_workspace_bytes(int N);
 hipError_t launch_colsum(const float* X, int64_t ldx, const float* w, int64_t M, int N, float* out, float* partial,
                          hipStream_t stream);
+// out[n] = sum_s partial[s][n] in a fixed order (second stage of launch_colsum; also reduces GemmArgs::colsum)
+hipError_t launch_colsum_final(const float* partial, int nsplit, int N, float* out, hipStream_t stream);
 hipError_t launch_dot_scoring_bwd(const float* u, const float* c, const float* dr, float* du, float* dc, int64_t B, int32_t C,
                                   int32_t E, hipStream_t stream);
 hipError_t launch_dot_scoring_norm_bwd(const float* u, const float* c, const float* dr, float* du, float* dc, int64_t B,

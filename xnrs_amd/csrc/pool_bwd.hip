@@ -138,6 +138,12 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial,
   if (lane == 0) out[n] = acc;
 }
 
+hipError_t launch_colsum_final(const float* partial, int nsplit, int N, float* out, hipStream_t stream) {
+  if (N <= 0) return hipSuccess;
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, partial, nsplit, N, out);
+  return hipGetLastError();
+}
+
 size_t colsum_workspace_bytes(int N) { return (size_t)COLSUM_MAX_SPLITS * (size_t)N * sizeof(float); }
 
 hipError_t launch_colsum(const float* X, int64_t ldx, const float* w, int64_t M, int N, float* out, float* partial,
