@@ -64,8 +64,12 @@ constexpr unsigned BUF_OOB = 0x40000000u;
 // GATH (with BUF): the rows of A are gathered (or A is too large for a buffer descriptor): A is read through per-thread
 // 64-bit row pointers, UNCONDITIONALLY -- rows past M are clamped to row M-1 (their results are never stored) and the k
 // tail is clamped to K-4 (it meets the zeros the bounds check returns for B) -- while B keeps the raw buffer loads.
-// No address selects and no zero line: 4 VGPRs more than the pure buffer-load kernel, still 4 workgroups per CU (the
-// first gather variant selected between row pointer and zero line per load: 139 VGPRs, 45 spills, 3 workgroups/CU, 5 %).
+// No address selects and no zero line: 2 spilled VGPRs and 8 VALU instructions per K tile more than the pure buffer-load
+// kernel, still 4 workgroups per CU.  Measured on the Q/K/V projection inside the B = 512 step (tools/bench_idpath.py,
+// same ids, interleaved): 37.5 ms gathered vs 35.5 ms dense = 5.9 % on that GEMM, 3.6 % on the step (the first gather
+// variant -- a select between row pointer and zero line per load, 139 VGPRs, 45 spills, 3 workgroups per CU -- cost
+// 7.1 % / 4.4 %).  A descriptor cannot do it: the rows of one tile belong to up to four news anywhere in a 10-GB table,
+// and a buffer / saddr offset reaches 4 GB from one wave-uniform base.
 template <int TM, int TN, bool A_COL, bool B_KN, bool VEC, int PIPE, int BK, bool BUF = false, int MINW = 2, bool GATH = false>
 __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_tiles, int n_tiles_seg, int gn) {
   static_assert(!BUF || (!A_COL && !B_KN && VEC), "buffer loads are implemented for the forward layout");
@@ -109,8 +113,10 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
   const int64_t m0 = (int64_t)mt * BM;
   const int n0 = nts * BN;  // column inside the segment
 
-  const int64_t kbeg = (int64_t)blockIdx.y * a.k_per_split;
-  const int64_t kend = (kbeg + a.k_per_split < a.K) ? kbeg + a.k_per_split : a.K;
+  // contraction indices are 32-bit in the kernel (the launcher refuses K >= 2^31): the k-tail tests and tile offsets of
+  // the inner loop are then single VALU / SALU instructions instead of 64-bit compare-and-select pairs
+  const int kbeg = (int)((int64_t)blockIdx.y * a.k_per_split);
+  const int kend = (int)((kbeg + a.k_per_split < a.K) ? kbeg + a.k_per_split : a.K);
 
   const float* __restrict__ W = a.W[seg];
   const float* __restrict__ bias = a.bias[seg];
@@ -192,14 +198,15 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
   // P = register set (compile-time), k0 = first k of the tile
   // `only` >= 0 restricts the call to ONE 16-byte chunk (A chunks 0..AR-1, then B chunks): the interleaved
   // pipeline issues the tile loads / LDS stores one at a time between MFMAs.
-  auto gload = [&](auto P, int64_t k0, int only = -1) {
+  auto gload = [&](auto P, int k0, int only = -1) {
     constexpr int p = decltype(P)::value;
     if constexpr (BUF) {
       const unsigned sel = (k0 + 4 * lc < kend) ? 0u : BUF_OOB;  // k tail of the last tile
       const int soff = (int)(k0 * 4);
-      int64_t ka = k0;  // GATH: clamp the k tail (B returns zeros there)
+      int ka = k0;  // GATH: clamp the k tail (B returns zeros there)
       if constexpr (GATH) {
-        if (ka + 4 * lc > kend - 4) ka = kend - 4 - 4 * lc;
+        const int klim = kend - 4 - 4 * lc;
+        ka = ka < klim ? ka : klim;
       }
 #pragma unroll
       for (int i = 0; i < AR; ++i)
@@ -376,8 +383,8 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
   using I0 = std::integral_constant<int, 0>;
   using I4 = std::integral_constant<int, BK / 8>;
 
-  const int nk = (int)((kend - kbeg + BK - 1) / BK);
-  auto ktile = [&](int t) { return kbeg + (int64_t)t * BK; };
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  auto ktile = [&](int t) { return kbeg + t * BK; };
   if constexpr (PIPE == 1) {
     // one tile ahead: loads of tile t+1 fly during the MFMAs of tile t, LDS store at the end
     if (nk > 0) {
@@ -438,7 +445,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
     __syncthreads();
     for (int t = 0; t < nk; ++t) {
       const int buf = t & 1;
-      const int64_t kn = ktile(t + 2 < last ? t + 2 : last);
+      const int kn = ktile(t + 2 < last ? t + 2 : last);
       ldfrag(0, buf, 0);
 #pragma unroll
       for (int kq = 0; kq < NKQ; ++kq) {
@@ -693,6 +700,7 @@ void set_gemm_mode(int mode) { g_gemm_mode.store((mode >= 0 && mode <= 2) ? mode
 hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t stream, int* nsplit_used) {
   GemmArgs a = a_in;
   if (a.M <= 0 || a.Nseg <= 0) return hipSuccess;
+  if (a.K >= (1ll << 31)) return hipErrorInvalidValue;  // 32-bit contraction indices in the kernel
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   // 16-byte vector loads need the contiguous dimension of each operand on 16-B boundaries
   bool vec = (a.lda % 4 == 0) && (a.ldw % 4 == 0) && al16(a.A);
