@@ -180,6 +180,18 @@ int32_t xnrs_seq_encoder_fwd_train(const float *x, const float *m, const int32_t
                                    int32_t D, const xnrs_mha_params *att, int32_t pool_kind,
                                    const xnrs_additive_params *pool, const xnrs_head_params *head, float *y,
                                    float *a_out, float *hm, void *saved, size_t saved_bytes, void *stream);
+/* The same forward computing only what can reach the output or a gradient (optional; identical results): with
+ * live_rows / live_src_rows / n_live as in xnrs_seq_encoder_bwd_live below, the query projection, the output projection
+ * and fc1 run over the unmasked token rows in place and the masked rows of Q, Y and T are stored as zeros (a masked
+ * row's pooling weight is exp(e) * 0: nothing downstream, forward or backward, depends on its values; K and V stay
+ * dense because the reference masks query rows only, layers.py:142-144).  Used only with attention + additive pooling
+ * + a mask; live_rows == NULL = xnrs_seq_encoder_fwd_train. */
+int32_t xnrs_seq_encoder_fwd_train_live(const float *x, const float *m, const int32_t *ids, int64_t n_seq, int32_t L,
+                                        int32_t D, const xnrs_mha_params *att, int32_t pool_kind,
+                                        const xnrs_additive_params *pool, const xnrs_head_params *head, float *y,
+                                        float *a_out, float *hm, void *saved, size_t saved_bytes,
+                                        const int32_t *live_rows, const int32_t *live_src_rows, int64_t n_live,
+                                        void *stream);
 size_t xnrs_seq_encoder_bwd_workspace_bytes(int64_t n_seq, int32_t L, int32_t D, int32_t A, int32_t E,
                                             int32_t n_heads, int32_t pool_kind, int32_t has_head);
 int32_t xnrs_seq_encoder_bwd(const float *x, const float *m, const int32_t *ids, int64_t n_seq, int32_t L, int32_t D,

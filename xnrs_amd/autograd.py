@@ -74,7 +74,8 @@ def _ref(s):
     return None if s is None else C.byref(s)
 
 
-#: backward over the unmasked token rows only (exact; include/xnrs_hip.h: xnrs_seq_encoder_bwd_live).  Environment
+#: forward and backward over the unmasked token rows only (exact; include/xnrs_hip.h: xnrs_seq_encoder_fwd_train_live /
+#: xnrs_seq_encoder_bwd_live).  Environment
 #: XNRS_BWD_LIVE_ROWS=0 turns it off; it is used when at most LIVE_ROWS_MAX_FRACTION of the rows are unmasked.
 LIVE_ROWS = os.environ.get("XNRS_BWD_LIVE_ROWS", "1") != "0"
 LIVE_ROWS_MAX_FRACTION = 0.9
@@ -97,9 +98,25 @@ class _SeqEncode(torch.autograd.Function):
         l = hip.lib()
         nsaved = l.xnrs_seq_encoder_saved_bytes(n, L, D, cfg.A, Eo, cfg.n_heads, cfg.pool_kind, int(cfg.has_head))
         saved = torch.empty(max(nsaved, 1), dtype=torch.uint8, device=dev)
-        hip.check(l.xnrs_seq_encoder_fwd_train(hip.ptr(x), hip.ptr(m), hip.ptr(ids), n, L, D, _ref(ap), cfg.pool_kind,
-                                               _ref(pp), _ref(hp), hip.ptr(y), hip.ptr(a), hip.ptr(hm), hip.ptr(saved),
-                                               nsaved, hip.stream_ptr(dev)), "xnrs_seq_encoder_fwd_train")
+        # Nothing that flows through a masked token row reaches the output or a gradient (its pooling weight is
+        # exp(e)*0), so the row-parallel products of an attention tower -- forward (query projection, output projection,
+        # fc1) and backward -- run over the unmasked rows only (xnrs_seq_encoder_fwd_train_live / _bwd_live).  Index
+        # bookkeeping with torch (one host sync for the count); skipped when few rows are masked.
+        live = live_src = None
+        n_live = 0
+        if LIVE_ROWS and m is not None and cfg.n_heads > 0 and cfg.pool_kind == hip.POOL_ADDITIVE and n * L >= 4096:
+            lm = (m[ids.long()] if ids is not None else m).reshape(-1).ne(0)
+            rows_live = lm.nonzero().squeeze(1)
+            if rows_live.numel() <= LIVE_ROWS_MAX_FRACTION * n * L:
+                live, n_live = rows_live.to(torch.int32), rows_live.numel()
+                if ids is not None:
+                    seq = torch.div(rows_live, L, rounding_mode="floor")
+                    live_src = (ids.long()[seq] * L + (rows_live - seq * L)).to(torch.int32)
+        hip.check(l.xnrs_seq_encoder_fwd_train_live(hip.ptr(x), hip.ptr(m), hip.ptr(ids), n, L, D, _ref(ap), cfg.pool_kind,
+                                                    _ref(pp), _ref(hp), hip.ptr(y), hip.ptr(a), hip.ptr(hm), hip.ptr(saved),
+                                                    nsaved, hip.ptr(live), hip.ptr(live_src), n_live, hip.stream_ptr(dev)),
+                  "xnrs_seq_encoder_fwd_train_live")
+        ctx.live, ctx.live_src, ctx.n_live = live, live_src, n_live
         ctx.cfg = cfg
         ctx.nsaved = nsaved
         ctx.n_params = len(params)
@@ -142,19 +159,7 @@ class _SeqEncode(torch.autograd.Function):
         l = hip.lib()
         nws = l.xnrs_seq_encoder_bwd_workspace_bytes(n, L, D, cfg.A, Eo, cfg.n_heads, cfg.pool_kind, int(cfg.has_head))
         ws = hip.workspace(dev, nws)
-        # Every gradient through a masked token row is exactly zero (its pooling weight is exp(e)*0), so the
-        # row-parallel products of an attention tower run over the unmasked rows only (xnrs_seq_encoder_bwd_live).
-        # Index bookkeeping with torch (one host sync for the count); skipped when few rows are masked.
-        live = live_src = None
-        n_live = 0
-        if LIVE_ROWS and m is not None and cfg.n_heads > 0 and cfg.pool_kind == hip.POOL_ADDITIVE and n * L >= 4096:
-            lm = (m[ids.long()] if ids is not None else m).reshape(-1).ne(0)
-            rows_live = lm.nonzero().squeeze(1)
-            if rows_live.numel() <= LIVE_ROWS_MAX_FRACTION * n * L:
-                live, n_live = rows_live.to(torch.int32), rows_live.numel()
-                if ids is not None:
-                    seq = torch.div(rows_live, L, rounding_mode="floor")
-                    live_src = (ids.long()[seq] * L + (rows_live - seq * L)).to(torch.int32)
+        live, live_src, n_live = ctx.live, ctx.live_src, ctx.n_live  # the unmasked rows found by the forward
         hip.check(l.xnrs_seq_encoder_bwd_live(hip.ptr(x), hip.ptr(m), hip.ptr(ids), n, L, D, _ref(ap), cfg.pool_kind, _ref(pp),
                                               _ref(hp), hip.ptr(saved), ctx.nsaved, hip.ptr(dy), hip.ptr(dx), _ref(ga),
                                               _ref(gp), _ref(gh), hip.ptr(live), hip.ptr(live_src), n_live, hip.ptr(ws), nws,

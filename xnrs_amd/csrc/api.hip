@@ -153,7 +153,8 @@ GemmArgs gemm1(const float* A, const int32_t* ids, int gS, int64_t lda, const fl
 int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n_seq, int L, int D,
                    const xnrs_mha_params* att, bool pooled, int pool_kind, const xnrs_additive_params* pool,
                    const xnrs_head_params* head, float* y, float* a_out, float* hm, int64_t chunk, void* ws,
-                   size_t ws_bytes, hipStream_t stream, bool train = false) {
+                   size_t ws_bytes, hipStream_t stream, bool train = false, const int32_t* live_rows = nullptr,
+                   const int32_t* live_src_rows = nullptr, int64_t n_live = 0) {
   if (n_seq == 0) return XNRS_OK;
   if (n_seq < 0 || L <= 0 || D <= 0 || !x || !y) return XNRS_EINVAL;
   if (att) {
@@ -185,6 +186,16 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
   float* t = reinterpret_cast<float*>(w + p.off_t);
   float* pb = reinterpret_cast<float*>(w + p.off_p);
   float* hb = reinterpret_cast<float*>(w + p.off_h);
+
+  // Training forward over the UNMASKED token rows (optional, exact): a masked token row has pooling weight exp(e) * 0, so
+  // its query projection, its out-projection row and its fc1 row never reach the output or any gradient (K and V stay
+  // dense: padded tokens are keys, layers.py:142-144).  Those three products run over the live rows in place (A rows
+  // gathered, C rows scattered through the same list); the dead rows of Q, Y and T are ZEROED first, which keeps every
+  // later consumer -- attention core, pooling, and the backward kernels that read the saved activations -- finite and
+  // exactly as if the rows had been computed and then multiplied by the zero weight.
+  const bool live = train && att && additive && m && live_rows && n_live >= 0 && n_live < n_seq * L &&
+                    !(ids && !live_src_rows);
+  const int32_t* lvx = live ? (ids ? live_src_rows : live_rows) : nullptr;  // rows of x (table rows with ids)
 
   // bf16-split GEMM modes: split the weights ONCE per call (the chunk loop below reuses them ~20 times per step)
   const unsigned short *pq = nullptr, *pk = nullptr, *pv = nullptr, *po = nullptr, *p1 = nullptr;
@@ -261,7 +272,22 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
       g.K = D;
       g.act = XNRS_ACT_NONE;
       const int dk = D / att->n_heads;
-      {
+      if (live) {  // K|V of every row, Q of the live rows only (dead Q rows = 0)
+        ProfScope ps(0, 2.0 * rows * 2.0 * D * D + 2.0 * n_live * (double)D * D, stream);
+        g.W[0] = att->wk; g.W[1] = att->wv; g.W[2] = nullptr;
+        g.Wp[0] = pk; g.Wp[1] = pv; g.Wp[2] = nullptr;
+        g.bias[0] = att->bk; g.bias[1] = att->bv; g.bias[2] = nullptr;
+        g.nseg = 2;
+        g.C = qkv + D;
+        XNRS_TRY(launch_gemm_f32(g, stream));
+        XNRS_TRY(hipMemset2DAsync(qkv, (size_t)3 * D * sizeof(float), 0, (size_t)D * sizeof(float), (size_t)rows, stream));
+        if (n_live > 0) {
+          GemmArgs q = gemm1(cx, lvx, 1, D, att->wq, att->bq, qkv, 3 * (int64_t)D, n_live, D, D, XNRS_ACT_NONE, pq);
+          q.c_scatter = 1;
+          q.c_scatter_ids = live_rows;
+          XNRS_TRY(launch_gemm_f32(q, stream));
+        }
+      } else {
         ProfScope ps(0, 2.0 * rows * 3.0 * D * D, stream);
         XNRS_TRY(launch_gemm_f32(g, stream));
       }
@@ -294,7 +320,15 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
       }
 
       float* dst = pooled ? yb : y + c0 * (int64_t)L * D;
-      {
+      if (live) {
+        ProfScope ps(2, 2.0 * n_live * (double)D * D, stream);
+        XNRS_TRY(hipMemsetAsync(dst, 0, (size_t)rows * D * sizeof(float), stream));
+        if (n_live > 0) {
+          GemmArgs og = gemm1(o, live_rows, 1, D, att->wo, att->bo, dst, D, n_live, D, D, XNRS_ACT_NONE, po);
+          og.c_scatter = 1;
+          XNRS_TRY(launch_gemm_f32(og, stream));
+        }
+      } else {
         ProfScope ps(2, 2.0 * rows * (double)D * D, stream);
         XNRS_TRY(launch_gemm_f32(gemm1(o, nullptr, 0, D, att->wo, att->bo, dst, D, rows, D, D, XNRS_ACT_NONE, po), stream));
       }
@@ -306,7 +340,15 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
     float* pooled_dst = (head ? pb : y) + c0 * (int64_t)D;
     float* hm_dst = hm ? hm + c0 : nullptr;
     if (additive) {
-      {
+      if (live) {  // (live implies att: seq is the dense attention output, no id gather left)
+        ProfScope ps(3, 2.0 * n_live * (double)D * A, stream);
+        XNRS_TRY(hipMemsetAsync(t, 0, (size_t)rows * A * sizeof(float), stream));
+        if (n_live > 0) {
+          GemmArgs fg = gemm1(seq, live_rows, 1, D, pool->w1, pool->b1, t, A, n_live, A, D, XNRS_ACT_TANH, p1);
+          fg.c_scatter = 1;
+          XNRS_TRY(launch_gemm_f32(fg, stream));
+        }
+      } else {
         ProfScope ps(3, 2.0 * rows * (double)D * A, stream);
         XNRS_TRY(launch_gemm_f32(gemm1(seq, seq_ids, L, D, pool->w1, pool->b1, t, A, rows, A, D, XNRS_ACT_TANH, p1), stream));
       }
@@ -803,9 +845,19 @@ int32_t xnrs_seq_encoder_fwd_train(const float* x, const float* m, const int32_t
                                    const xnrs_mha_params* att, int32_t pool_kind, const xnrs_additive_params* pool,
                                    const xnrs_head_params* head, float* y, float* a_out, float* hm, void* saved,
                                    size_t saved_bytes, void* stream) {
+  return xnrs_seq_encoder_fwd_train_live(x, m, ids, n_seq, L, D, att, pool_kind, pool, head, y, a_out, hm, saved, saved_bytes,
+                                         nullptr, nullptr, 0, stream);
+}
+
+int32_t xnrs_seq_encoder_fwd_train_live(const float* x, const float* m, const int32_t* ids, int64_t n_seq, int32_t L, int32_t D,
+                                        const xnrs_mha_params* att, int32_t pool_kind, const xnrs_additive_params* pool,
+                                        const xnrs_head_params* head, float* y, float* a_out, float* hm, void* saved,
+                                        size_t saved_bytes, const int32_t* live_rows, const int32_t* live_src_rows,
+                                        int64_t n_live, void* stream) {
   const bool pooled = pool_kind != XNRS_POOL_NONE;
+  if (live_rows && ids && !live_src_rows) return XNRS_EINVAL;  // a gathered table needs the table rows of the live tokens
   return seq_encode(x, m, ids, n_seq, L, D, att, pooled, pool_kind, pool, pooled ? head : nullptr, y, a_out, hm, 0, saved,
-                    saved_bytes, (hipStream_t)stream, true);
+                    saved_bytes, (hipStream_t)stream, true, live_rows, live_src_rows, n_live);
 }
 
 size_t xnrs_seq_encoder_bwd_workspace_bytes(int64_t n_seq, int32_t L, int32_t D, int32_t A, int32_t E, int32_t n_heads,

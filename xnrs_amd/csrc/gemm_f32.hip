@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
         if (row < a.M) {
           if (!A_COL && a.c_scatter) {  // row subset in place: C (and aux) rows follow A's gather
             const int64_t n = row / a.gather_S;
-            row = (int64_t)a.gather_ids[n] * a.gather_S + (row - n * a.gather_S);
+            row = (int64_t)(a.c_scatter_ids ? a.c_scatter_ids : a.gather_ids)[n] * a.gather_S + (row - n * a.gather_S);
           }
           float v = acc[i][j][e];
           if (!split) {
@@ -587,7 +587,7 @@ static hipError_t launch_cfg(const GemmArgs& a, bool vec, int nsplit, hipStream_
   const bool buf = bufB && !a.gather_ids && a.M * a.lda * 4 <= (int64_t)BUF_OOB;
   // gathered rows / an A operand beyond the 1-GB descriptor window: pointers for A, buffer loads for B (K >= 4: the
   // k-tail clamp reads K-4 .. K-1)
-  const bool gath = bufB && !buf && !a.c_scatter && a.K >= 4;
+  const bool gath = bufB && !buf && a.K >= 4;  // (row scatter of C is an epilogue matter: any A-load variant serves it)
 #define XNRS_LAUNCH(VECV, PIPEV, BKV, BUFV, MINWV)                                                                  \
   hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, A_COL, B_KN, VECV, PIPEV, BKV, BUFV, MINWV>), g, dim3(256), 0, stream, a, \
                      (int)m_tiles, n_tiles_seg, gn)

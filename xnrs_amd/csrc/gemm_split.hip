@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_split_kernel(GemmArgs a, int m
         if (row < a.M) {
           if (a.c_scatter) {  // row subset in place (see gemm_f32_kernel)
             const int64_t n = row / a.gather_S;
-            row = (int64_t)a.gather_ids[n] * a.gather_S + (row - n * a.gather_S);
+            row = (int64_t)(a.c_scatter_ids ? a.c_scatter_ids : a.gather_ids)[n] * a.gather_S + (row - n * a.gather_S);
           }
           float v = acc[i][j][e] + bv;
           if (a.act == 1) v = fmaxf(v, 0.f);

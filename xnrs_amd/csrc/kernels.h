@@ -44,6 +44,8 @@ struct GemmArgs {
   int32_t gather_S;
   int32_t c_scatter;          // 1 (ROW A with gather_ids): logical row m of C is that same physical row -- the GEMM
                               // works on a row subset of A and C in place (backward over the unmasked token rows)
+  const int32_t* c_scatter_ids;  // nullable, with c_scatter: the C rows follow THIS list instead of gather_ids (A rows
+                                 // gathered from a news table, C rows in the batch's own row space)
   int64_t lda;
   const float* W[3];
   const float* bias[3];  // nullable each

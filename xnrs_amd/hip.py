@@ -26,7 +26,8 @@ SYMBOLS = (
     "xnrs_user_encoder_fwd", "xnrs_dot_scoring_fwd", "xnrs_profile_enable", "xnrs_profile_read",
     "xnrs_set_gemm_mode", "xnrs_get_gemm_mode", "xnrs_reload_knobs",
     "xnrs_text_encoder_unpadded_workspace_bytes", "xnrs_text_encoder_fwd_unpadded",
-    "xnrs_seq_encoder_saved_bytes", "xnrs_seq_encoder_fwd_train", "xnrs_seq_encoder_bwd_workspace_bytes",
+    "xnrs_seq_encoder_saved_bytes", "xnrs_seq_encoder_fwd_train", "xnrs_seq_encoder_fwd_train_live",
+    "xnrs_seq_encoder_bwd_workspace_bytes",
     "xnrs_seq_encoder_bwd", "xnrs_seq_encoder_bwd_live", "xnrs_linear_bwd_workspace_bytes", "xnrs_linear_bwd",
     "xnrs_embedding_linear_bwd_workspace_bytes", "xnrs_embedding_linear_bwd", "xnrs_dot_scoring_bwd", "xnrs_dot_scoring_norm_bwd",
     "xnrs_assemble_train_batch", "xnrs_assemble_eval_batch", "xnrs_score_csr", "xnrs_rank_metrics", "xnrs_gather_rows",
@@ -119,6 +120,9 @@ def lib():
     l.xnrs_seq_encoder_fwd_train.restype = i32
     l.xnrs_seq_encoder_fwd_train.argtypes = [p, p, p, i64, i32, i32, C.POINTER(MhaParams), i32, C.POINTER(AdditiveParams),
                                              C.POINTER(HeadParams), p, p, p, p, sz, p]
+    l.xnrs_seq_encoder_fwd_train_live.restype = i32
+    l.xnrs_seq_encoder_fwd_train_live.argtypes = [p, p, p, i64, i32, i32, C.POINTER(MhaParams), i32, C.POINTER(AdditiveParams),
+                                                  C.POINTER(HeadParams), p, p, p, p, sz, p, p, i64, p]
     l.xnrs_seq_encoder_bwd_workspace_bytes.restype = sz
     l.xnrs_seq_encoder_bwd_workspace_bytes.argtypes = [i64, i32, i32, i32, i32, i32, i32, i32]
     l.xnrs_seq_encoder_bwd.restype = i32
