@@ -280,7 +280,7 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
         g.nseg = 2;
         g.C = qkv + D;
         XNRS_TRY(launch_gemm_f32(g, stream));
-        XNRS_TRY(hipMemset2DAsync(qkv, (size_t)3 * D * sizeof(float), 0, (size_t)D * sizeof(float), (size_t)rows, stream));
+        XNRS_TRY(launch_zero_cols(qkv, 3 * (int64_t)D, D, rows, stream));
         if (n_live > 0) {
           GemmArgs q = gemm1(cx, lvx, 1, D, att->wq, att->bq, qkv, 3 * (int64_t)D, n_live, D, D, XNRS_ACT_NONE, pq);
           q.c_scatter = 1;

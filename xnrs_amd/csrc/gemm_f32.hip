@@ -243,14 +243,20 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
         if (only >= 0 && only != i) continue;
-        const int64_t k = k0 + kA + KRA * i;
+        const int k = k0 + kA + KRA * i;
         const bool kok = k < kend;
-        int64_t srck = kok ? k : kbeg;
+        // k-row gather in 32-bit arithmetic (the contraction is < 2^31), and with NO division for the one-row-per-id
+        // lists of the live-row backward: the 64-bit `srck / gather_S` of the first version was a software division
+        // per tile load -- 3.4 VALU instructions per MFMA in the dW GEMMs (profiles/r02_train_step_pmc.txt)
+        int srck = kok ? k : kbeg;
         if (a.gather_ids) {
-          const int64_t n = srck / a.gather_S;
-          srck = (int64_t)a.gather_ids[n] * a.gather_S + (srck - n * a.gather_S);
+          if (a.gather_S == 1) srck = a.gather_ids[srck];
+          else {
+            const int n = srck / a.gather_S;
+            srck = a.gather_ids[n] * a.gather_S + (srck - n * a.gather_S);
+          }
         }
-        const float* ptr = a.A + srck * a.lda;
+        const float* ptr = a.A + (int64_t)srck * a.lda;
         if (VEC) {
           ra[p][i] = *reinterpret_cast<const f32x4*>((kok && a_ok) ? ptr + mi : g_zero_line);
         } else {
@@ -287,14 +293,17 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
 #pragma unroll
       for (int i = 0; i < BR; ++i) {
         if (only >= 0 && only != AR + i) continue;
-        const int64_t k = k0 + kB + KRB * i;
+        const int k = k0 + kB + KRB * i;
         const bool kok = k < kend;
-        int64_t src = kok ? k : kbeg;
+        int src = kok ? k : kbeg;
         if (a.b_gather_ids) {
-          const int64_t n = src / a.b_gather_S;
-          src = (int64_t)a.b_gather_ids[n] * a.b_gather_S + (src - n * a.b_gather_S);
+          if (a.b_gather_S == 1) src = a.b_gather_ids[src];
+          else {
+            const int n = src / a.b_gather_S;
+            src = a.b_gather_ids[n] * a.b_gather_S + (src - n * a.b_gather_S);
+          }
         }
-        const float* ptr = W + src * a.ldw;
+        const float* ptr = W + (int64_t)src * a.ldw;
         if (VEC) {
           rb[p][i] = *reinterpret_cast<const f32x4*>((kok && b_ok) ? ptr + ni : g_zero_line);
         } else {
@@ -541,6 +550,25 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* W, float* W
     const int c = c0 + ty + 8 * i, r = r0 + tx;
     if (r < rows && c < cols) Wt[(int64_t)c * rows + r] = tile[tx][ty + 8 * i];
   }
+}
+
+// zero `width` floats (multiple of 4, 16-byte aligned) of each of `rows` rows of pitch `ld` floats: the column block of
+// one segment inside a [rows, 3D] image.  (hipMemset2DAsync took 311 us for 80 000 x 768 floats, this runs at HBM speed.)
+__global__ __launch_bounds__(256) void zero_cols_kernel(float* p, int64_t ld, int w4, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int64_t r = i / w4;
+  const int c = (int)(i - r * w4);
+  __builtin_nontemporal_store(f32x4{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f32x4*>(p + r * ld) + c);
+}
+
+hipError_t launch_zero_cols(float* p, int64_t ld, int width, int64_t rows, hipStream_t stream) {
+  if (rows <= 0 || width <= 0) return hipSuccess;
+  if (width % 4 != 0 || ld % 4 != 0 || (reinterpret_cast<uintptr_t>(p) & 15) != 0)
+    return hipMemset2DAsync(p, (size_t)ld * sizeof(float), 0, (size_t)width * sizeof(float), (size_t)rows, stream);
+  const int64_t n4 = rows * (width / 4);
+  hipLaunchKernelGGL(zero_cols_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, p, ld, width / 4, n4);
+  return hipGetLastError();
 }
 
 hipError_t launch_transpose(const float* W, float* Wt, int rows, int cols, hipStream_t stream) {

@@ -79,6 +79,8 @@ struct GemmArgs {
   int64_t k_per_split;  // filled in by the launcher
   int64_t slab_stride;  // filled in by the launcher
 };
+// zero a [rows, width] column block of a row-major image of pitch ld (floats)
+hipError_t launch_zero_cols(float* p, int64_t ld, int width, int64_t rows, hipStream_t stream);
 // Wt[c][r] = W[r][c] for a small row-major matrix W[rows][cols] (weights: a few MB)
 hipError_t launch_transpose(const float* W, float* Wt, int rows, int cols, hipStream_t stream);
 int gemm_pick_splits(int64_t M, int64_t N, int64_t K);
