@@ -70,7 +70,13 @@ constexpr unsigned BUF_OOB = 0x40000000u;
 // variant -- a select between row pointer and zero line per load, 139 VGPRs, 45 spills, 3 workgroups per CU -- cost
 // 7.1 % / 4.4 %).  A descriptor cannot do it: the rows of one tile belong to up to four news anywhere in a 10-GB table,
 // and a buffer / saddr offset reaches 4 GB from one wave-uniform base.
-template <int TM, int TN, bool A_COL, bool B_KN, bool VEC, int PIPE, int BK, bool BUF = false, int MINW = 2, bool GATH = false>
+// KG (k-major operands): how the k rows are gathered -- 0: not at all; 1: both operands through one-row-per-id lists
+// (the live-row backward); 2: anything else, decided at run time.  A template parameter because the run-time tests
+// (`if (gather_ids) { if (S == 1) ...`) sat in front of each of the 8 tile loads of an iteration: 29 basic blocks, the
+// interleaved MFMA / load schedule gone, 3.4 VALU instructions per MFMA and 65 % matrix-pipe occupancy in the dW GEMMs
+// (profiles/r02_train_step_pmc.txt).
+template <int TM, int TN, bool A_COL, bool B_KN, bool VEC, int PIPE, int BK, bool BUF = false, int MINW = 2, bool GATH = false,
+          int KG = 2>
 __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_tiles, int n_tiles_seg, int gn) {
   static_assert(!BUF || (!A_COL && !B_KN && VEC), "buffer loads are implemented for the forward layout");
   static_assert(!GATH || BUF, "the gathered-A variant keeps buffer loads for B");
@@ -249,11 +255,15 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
         // lists of the live-row backward: the 64-bit `srck / gather_S` of the first version was a software division
         // per tile load -- 3.4 VALU instructions per MFMA in the dW GEMMs (profiles/r02_train_step_pmc.txt)
         int srck = kok ? k : kbeg;
-        if (a.gather_ids) {
-          if (a.gather_S == 1) srck = a.gather_ids[srck];
-          else {
-            const int n = srck / a.gather_S;
-            srck = a.gather_ids[n] * a.gather_S + (srck - n * a.gather_S);
+        if constexpr (KG == 1) {
+          srck = a.gather_ids[srck];
+        } else if constexpr (KG == 2) {
+          if (a.gather_ids) {
+            if (a.gather_S == 1) srck = a.gather_ids[srck];
+            else {
+              const int n = srck / a.gather_S;
+              srck = a.gather_ids[n] * a.gather_S + (srck - n * a.gather_S);
+            }
           }
         }
         const float* ptr = a.A + (int64_t)srck * a.lda;
@@ -296,11 +306,15 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
         const int k = k0 + kB + KRB * i;
         const bool kok = k < kend;
         int src = kok ? k : kbeg;
-        if (a.b_gather_ids) {
-          if (a.b_gather_S == 1) src = a.b_gather_ids[src];
-          else {
-            const int n = src / a.b_gather_S;
-            src = a.b_gather_ids[n] * a.b_gather_S + (src - n * a.b_gather_S);
+        if constexpr (KG == 1) {
+          src = a.b_gather_ids[src];
+        } else if constexpr (KG == 2) {
+          if (a.b_gather_ids) {
+            if (a.b_gather_S == 1) src = a.b_gather_ids[src];
+            else {
+              const int n = src / a.b_gather_S;
+              src = a.b_gather_ids[n] * a.b_gather_S + (src - n * a.b_gather_S);
+            }
           }
         }
         const float* ptr = W + (int64_t)src * a.ldw;
@@ -639,8 +653,20 @@ static hipError_t launch_cfg(const GemmArgs& a, bool vec, int nsplit, hipStream_
     if (buf) XNRS_LAUNCH(true, 5, 16, true, 4);
     else if (gath) XNRS_LAUNCH_GATH(4);
     else XNRS_LAUNCH(true, 5, 16, false, 4);
+  } else if constexpr (A_COL && B_KN) {
+    // backward dW = dY^T . X (both operands k-major): BK 32, 2 workgroups per CU (BK 16 / 4 per CU measured no better);
+    // one instantiation per k-row gather mode
+    const bool g_none = !a.gather_ids && !a.b_gather_ids;
+    const bool g_live = a.gather_ids && a.b_gather_ids && a.gather_S == 1 && a.b_gather_S == 1;
+#define XNRS_LAUNCH_KG(KGV)                                                                                              \
+  hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, A_COL, B_KN, true, 5, 32, false, 2, false, KGV>), g, dim3(256), 0, stream, a, \
+                     (int)m_tiles, n_tiles_seg, gn)
+    if (g_none) XNRS_LAUNCH_KG(0);
+    else if (g_live) XNRS_LAUNCH_KG(1);
+    else XNRS_LAUNCH_KG(2);
+#undef XNRS_LAUNCH_KG
   } else {
-    XNRS_LAUNCH(true, 5, 32, false, 2);  // backward (k-major) layouts: BK 16 / 4 WG per CU measured no better
+    XNRS_LAUNCH(true, 5, 32, false, 2);  // ROW x KN (small-M dX products)
   }
 #undef XNRS_LAUNCH
 #undef XNRS_LAUNCH_GATH
