@@ -387,3 +387,50 @@ def test_backward_over_live_rows_matches_dense_backward(with_ids):
         (yo[0] * w).sum().backward()
         H.assert_close(dx1, xo.grad, GTOL, "dx vs oracle")
         assert check_param_grads(enc, osd) >= 12
+
+
+@pytest.mark.parametrize("with_ids", [False, True])
+@pytest.mark.parametrize("live", [False, True])
+def test_weight_gradient_kernels_agree(with_ids, live):
+    """The register-transposing weight-gradient kernel (gemm_dw.hip; XNRS_GEMM_DW=2 sends every eligible launch to
+    it: dense rows, live-row lists, table-gathered X) against the generic k-major kernel (XNRS_GEMM_DW=0) on a
+    contraction long enough to qualify (>= 8192 rows), widths that leave a ragged 128-tile, and a split-K count that
+    is not a multiple of the 8 XCDs."""
+    from xnrs_amd import autograd as AG, hip
+    S, D, h, E = 24, 96, 4, 32
+    enc, sd = load(news_encoding.TextEncoder(pooler=layers.AdditiveAttention(D, 80), p_dropout=0.0, out_features=E,
+                                             in_features=D, att=layers.MultiHeadAttention(h, D)), 181)
+    rng = synth.rng_for(182)
+    n_tab, n_news = 900, 1000
+    x = torch.from_numpy(rng.standard_normal((n_tab, S, D)).astype("float32"))
+    m = torch.from_numpy((rng.random((n_tab, S)) < 0.6).astype("float32"))
+    m[:7] = 0
+    w = torch.from_numpy(rng.standard_normal((n_news if with_ids else n_tab, E)).astype("float32")).to(DEV)
+    ids = torch.from_numpy(rng.integers(0, n_tab, size=(n_news,)).astype("int64")) if with_ids else None
+
+    def run(knob):
+        with hip.knobs(XNRS_GEMM_DW=knob):
+            AG.LIVE_ROWS = live
+            try:
+                enc.zero_grad(set_to_none=True)
+                xd = x.to(DEV)
+                if with_ids:
+                    y, _ = enc.forward_ids(xd, m.to(DEV), ids.to(DEV).reshape(1, -1))
+                else:
+                    y, _ = enc((xd.unsqueeze(0), m.to(DEV).reshape(1, n_tab, S, 1)))
+                (y[0] * w).sum().backward()
+            finally:
+                AG.LIVE_ROWS = True
+        return {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None}
+
+    g0, g2 = run("0"), run("2")
+    assert g0.keys() == g2.keys() and len(g0) >= 12
+    gmax = max(v.abs().max().item() for v in g0.values())
+    for k in g0:  # (the key bias gradient is exactly zero in exact arithmetic: softmax shift invariance -> floor the scale)
+        scale = max(g0[k].abs().max().item(), 1e-3 * gmax)
+        assert (g2[k] - g0[k]).abs().max().item() / scale <= 2e-5, f"{k}: gemm_dw vs k-major kernel"
+    if not with_ids:
+        osd = oracle_sd(sd)
+        yo, _ = O.text_encoder(x.unsqueeze(0), m.reshape(1, n_tab, S, 1), osd, h)
+        (yo[0] * w.cpu()).sum().backward()
+        assert check_param_grads(enc, osd) >= 12

@@ -774,7 +774,7 @@ hipError_t gemm_dw(const float* dY, int64_t lddy, const float* X, const int32_t*
   g.ldc = K;
   g.M = N;
   g.K = M;
-  const int ns = gemm_pick_splits(N, K, M);
+  const int ns = gemm_pick_splits(N, K, M, knobs().gemm_dw && gemm_dw_eligible(g));
   if (ns > 1) {
     g.slabs = slabs;
     g.nsplit = ns;

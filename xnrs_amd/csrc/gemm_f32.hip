@@ -706,15 +706,16 @@ static hipError_t launch_layout(const GemmArgs& a, bool vec, int nsplit, hipStre
 }
 
 size_t gemm_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-  const int ns = gemm_pick_splits(M, N, K);
+  const int ns0 = gemm_pick_splits(M, N, K, false), ns1 = gemm_pick_splits(M, N, K, true);
+  const int ns = ns0 > ns1 ? ns0 : ns1;
   return ns > 1 ? (size_t)ns * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
 
-int gemm_pick_splits(int64_t M, int64_t N, int64_t K) {
-  // aim for one round of 128x128 workgroups (2 per CU x 256 CUs for the k-major variants) and at least 256
-  // contraction steps per slice
+int gemm_pick_splits(int64_t M, int64_t N, int64_t K, bool dw_kernel) {
+  // aim for one round of 128x128 workgroups (2 per CU x 256 CUs for the k-major variants, 3 per CU for gemm_dw.hip)
+  // and at least 256 contraction steps per slice
   const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
-  int64_t ns = 512 / tiles;
+  int64_t ns = (dw_kernel ? 768 : 512) / tiles;
   const int64_t max_by_k = K / 256;
   if (ns > max_by_k) ns = max_by_k;
   if (ns > 64) ns = 64;
@@ -738,6 +739,7 @@ static Knobs read_knobs() {
   k.mha_lds = (int)num("XNRS_MHA_LDS", -1);
   k.mha_headwave = num("XNRS_MHA_HEADWAVE", 1) != 0;
   k.mha_bwd_fused = num("XNRS_MHA_BWD_FUSED", 1) != 0;
+  k.gemm_dw = (int)num("XNRS_GEMM_DW", 1);
   k.news_fused = (int)num("XNRS_NEWS_FUSED", 1);
   k.news_fused_npw = (int)num("XNRS_NEWS_FUSED_NPW", 0);
   const long long m = num("XNRS_GEMM_MODE", 0);
@@ -787,7 +789,11 @@ hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t stream, int* nsplit
     return launch_gemm_split(a, mode == 1 ? 3 : 2, stream);
   if (!a.a_col && !a.b_kn) e = launch_layout<false, false>(a, vec, nsplit, stream);
   else if (!a.a_col && a.b_kn) e = launch_layout<false, true>(a, vec, nsplit, stream);
-  else if (a.a_col && a.b_kn) e = launch_layout<true, true>(a, vec, nsplit, stream);
+  else if (a.a_col && a.b_kn) {
+    // weight gradients: the register-transposing kernel (gemm_dw.hip) when the shape allows, else the k-major variant
+    if (knobs().gemm_dw && gemm_dw_eligible(a)) e = launch_gemm_dw(a, nsplit, stream);
+    else e = launch_layout<true, true>(a, vec, nsplit, stream);
+  }
   else return hipErrorInvalidValue;
   if (e != hipSuccess) return e;
   if (nsplit > 1) {

@@ -21,6 +21,7 @@ struct Knobs {
   long long gemm_group = -1;    // XNRS_GEMM_GROUP=n column tiles per walk group (0 = plain walk); -1 = automatic
   int gemm_tile = -1;           // XNRS_GEMM_TILE=0..3 force a block tile; -1 = cost model
   long long split_min_tiles = 512;  // XNRS_GEMM_SPLIT_MIN_TILES: smallest launch the bf16-split kernel takes
+  int gemm_dw = 1;              // XNRS_GEMM_DW: 1 = live-row weight gradients on gemm_dw.hip, 2 = every eligible one, 0 = none
   int mha_lds = -1;             // XNRS_MHA_LDS=0|1 force / forbid the LDS-staged attention kernel; -1 = by shape
   int mha_headwave = 1;         // XNRS_MHA_HEADWAVE=0: generic attention kernel only
   int mha_bwd_fused = 1;        // XNRS_MHA_BWD_FUSED=0: two-kernel attention backward
@@ -83,10 +84,14 @@ struct GemmArgs {
 hipError_t launch_zero_cols(float* p, int64_t ld, int width, int64_t rows, hipStream_t stream);
 // Wt[c][r] = W[r][c] for a small row-major matrix W[rows][cols] (weights: a few MB)
 hipError_t launch_transpose(const float* W, float* Wt, int rows, int cols, hipStream_t stream);
-int gemm_pick_splits(int64_t M, int64_t N, int64_t K);
+int gemm_pick_splits(int64_t M, int64_t N, int64_t K, bool dw_kernel = false);
 int gemm_group_tiles(int n_tiles, int bn, int64_t K, bool plain);
 size_t gemm_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
 hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t stream, int* nsplit_used = nullptr);
+// dW = dY^T . X with the transpose done in registers on the way to LDS (gemm_dw.hip); nsplit / k_per_split / slab_stride
+// as filled in by launch_gemm_f32
+bool gemm_dw_eligible(const GemmArgs& a);
+hipError_t launch_gemm_dw(const GemmArgs& a, int nsplit, hipStream_t stream);
 // forward-layout GEMM on the bf16 matrix cores by operand splitting (gemm_split.hip); npl = 3 or 2 planes
 hipError_t launch_gemm_split(const GemmArgs& a, int npl, hipStream_t stream);
 // planes[p][k/16][n][16] (p = 0..2: hi, mid, lo; k zero padded to ldp = split_plane_ld(K)) of W[N][K]: the
