@@ -63,13 +63,18 @@ constexpr unsigned BUF_OOB = 0x40000000u;
 
 // GATH (with BUF): the rows of A are gathered (or A is too large for a buffer descriptor): A is read through per-thread
 // 64-bit row pointers, UNCONDITIONALLY -- rows past M are clamped to row M-1 (their results are never stored) and the k
-// tail is clamped to K-4 (it meets the zeros the bounds check returns for B) -- while B keeps the raw buffer loads.
-// No address selects and no zero line: 2 spilled VGPRs and 8 VALU instructions per K tile more than the pure buffer-load
-// kernel, still 4 workgroups per CU.  Measured on the Q/K/V projection inside the B = 512 step (tools/bench_idpath.py,
-// same ids, interleaved): 37.5 ms gathered vs 35.5 ms dense = 5.9 % on that GEMM, 3.6 % on the step (the first gather
-// variant -- a select between row pointer and zero line per load, 139 VGPRs, 45 spills, 3 workgroups per CU -- cost
-// 7.1 % / 4.4 %).  A descriptor cannot do it: the rows of one tile belong to up to four news anywhere in a 10-GB table,
-// and a buffer / saddr offset reaches 4 GB from one wave-uniform base.
+// tail is clamped to K-4 (it meets the zeros the bounds check returns for B) -- while B keeps the raw buffer loads (one
+// VGPR offset per weight row here: the scalar-offset form of the dense kernel measured 1.5 % slower in this variant).
+// Measured inside the B = 512 step (tools/bench_idpath.py, same ids, interleaved): Q/K/V projection 37.6 ms gathered vs
+// 35.5 ms dense = 6 % on that GEMM, 3.7 % on the step (the first gather variant -- a select between row pointer and zero
+// line per load, 139 VGPRs, 45 spills, 3 workgroups per CU -- cost 7.1 % / 4.4 %).  What the rest is and is not:
+//   * not the random rows: the same kernel over a table that IS the materialised batch, ids = 0..n-1, takes the same
+//     time (bench_idpath.py "seq_ids") -- the cost is the per-lane 64-bit address form of the load;
+//   * a descriptor cannot replace it: the rows of one tile belong to up to four news anywhere in a 10-GB table; a raw
+//     buffer / saddr offset reaches 4 GB from one wave-uniform base, and a STRUCTURED buffer load (idxen: base + row
+//     index * 3072 + offset) wraps at the same 4 GB -- rows >= 2^32 / stride read as zeros (tools/probes/struct_buffer.hip);
+//   * advancing the row pointers in place (no clamp, no 64-bit temporaries, 4 instead of 12 extra VALU per K tile)
+//     measured SLOWER (6.3 % on the step): the add writes the address registers of the load issued just before it.
 // KG (k-major operands): how the k rows are gathered -- 0: not at all; 1: both operands through one-row-per-id lists
 // (the live-row backward); 2: anything else, decided at run time.  A template parameter because the run-time tests
 // (`if (gather_ids) { if (S == 1) ...`) sat in front of each of the 8 tile loads of an iteration: 29 basic blocks, the
@@ -147,29 +152,40 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
   const float* pa[AR];
   const float* pb[BR];
   unsigned a_ok = 0, b_ok = 0;  // bit i: row / column i of this thread is inside the matrix
-  unsigned offA[AR], offB[BR];  // BUF: byte offset of (row, chunk lc), or BUF_OOB
+  // BUF: ONE byte offset per operand in a VGPR -- (row lr, chunk lc) of the tile; row lr + RPP * i rides in the SCALAR
+  // offset (k0 * 4 + i * RPP * ld * 4), and rows / columns past the matrix need no flag: their offset is >= num_records
+  // (= rows * ld * 4) and the bounds check, which includes the scalar offset (tools/probes/raw_soffset.hip), returns
+  // zeros.  (With one VGPR offset per row the kernel sat at the 128-VGPR cap with 4 spilled loop invariants that were
+  // re-read from scratch -- through the same vmcnt queue as the tile loads -- in every K tile.)
+  unsigned offA0 = 0, offB0 = 0;
+  unsigned offBv[BR];  // GATH: one VGPR offset per weight row after all (measured faster there: see the GATH note above)
+  int dA = 0, dB = 0;
   __amdgpu_buffer_rsrc_t rsA, rsB;
   if constexpr (BUF) {
     if constexpr (!GATH) rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, (int)(a.M * a.lda * 4), 0x00020000);
     rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, (int)((int64_t)a.Nseg * a.ldw * 4), 0x00020000);
+    if constexpr (GATH) {
 #pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      const int64_t gr = m0 + lr + RPP * i;
-      if constexpr (GATH) {
+      for (int i = 0; i < AR; ++i) {
+        const int64_t gr = m0 + lr + RPP * i;
         int64_t src = gr < a.M ? gr : a.M - 1;
         if (a.gather_ids) {
           const int64_t n = src / a.gather_S;
           src = (int64_t)a.gather_ids[n] * a.gather_S + (src - n * a.gather_S);
         }
         pa[i] = a.A + src * a.lda + 4 * lc;
-      } else {
-        offA[i] = gr < a.M ? (unsigned)((gr * a.lda + 4 * lc) * 4) : BUF_OOB;
       }
+    } else {
+      const int64_t gr = m0 + lr;
+      offA0 = gr < a.M ? (unsigned)((gr * a.lda + 4 * lc) * 4) : BUF_OOB;
+      dA = (int)(RPP * a.lda * 4);
     }
+    const int col = n0 + lr;
+    offB0 = col < a.Nseg ? (unsigned)(((int64_t)col * a.ldw + 4 * lc) * 4) : BUF_OOB;
+    dB = (int)(RPP * a.ldw * 4);
+    if constexpr (GATH) {
 #pragma unroll
-    for (int i = 0; i < BR; ++i) {
-      const int col = n0 + lr + RPP * i;
-      offB[i] = col < a.Nseg ? (unsigned)(((int64_t)col * a.ldw + 4 * lc) * 4) : BUF_OOB;
+      for (int i = 0; i < BR; ++i) offBv[i] = offB0 + (unsigned)(i * dB);
     }
   } else if (!A_COL) {
 #pragma unroll
@@ -218,12 +234,14 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
       for (int i = 0; i < AR; ++i)
         if (only < 0 || only == i) {
           if constexpr (GATH) ra[p][i] = *reinterpret_cast<const f32x4*>(pa[i] + ka);
-          else ra[p][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)(offA[i] | sel), soff, 0));
+          else ra[p][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)(offA0 | sel), soff + i * dA, 0));
         }
 #pragma unroll
       for (int i = 0; i < BR; ++i)
-        if (only < 0 || only == AR + i)
-          rb[p][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(offB[i] | sel), soff, 0));
+        if (only < 0 || only == AR + i) {
+          if constexpr (GATH) rb[p][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(offBv[i] | sel), soff, 0));
+          else rb[p][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(offB0 | sel), soff + i * dB, 0));
+        }
       return;
     }
     if (!A_COL) {
