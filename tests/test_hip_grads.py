@@ -434,3 +434,40 @@ def test_weight_gradient_kernels_agree(with_ids, live):
         yo, _ = O.text_encoder(x.unsqueeze(0), m.reshape(1, n_tab, S, 1), osd, h)
         (yo[0] * w.cpu()).sum().backward()
         assert check_param_grads(enc, osd) >= 12
+
+
+@pytest.mark.parametrize("S,h,dk", [(33, 2, 48), (34, 3, 20), (36, 2, 64), (49, 2, 48), (50, 4, 48), (51, 2, 16),
+                                    (52, 3, 36), (37, 2, 48), (48, 2, 64), (53, 2, 20), (64, 2, 48), (50, 2, 4)])
+def test_attention_core_pair_kernel_branches(S, h, dk):
+    """mha_core_pair_kernel (mha_core.hip): every (full key tiles, tail keys) split -- S = 16 KTM + 1..4 goes through
+    the VALU tail, anything else through padded tiles -- times every feature-block count (d_k = 4 .. 64, with and
+    without feature padding), forward AND backward (the forward under grad keeps the softmax row statistics the
+    backward recomputes P from), against the oracle; and bitwise against the first-generation kernel where the two share their
+    arithmetic (no tail)."""
+    from xnrs_amd import hip
+    D = h * dk
+    att, sd = load(layers.MultiHeadAttention(h, D), 61)  # eval mode: no attention dropout; grads on: statistics kept
+    rng = synth.rng_for(62 + S)
+    n = 5
+    x = torch.from_numpy(rng.standard_normal((n, S, D)).astype("float32"))
+    m = torch.from_numpy(cases.block_mask(rng, n, S))
+    m[0] = 0  # a fully masked sequence: uniform 1/S rows over ALL keys, tail included
+    w = torch.from_numpy(rng.standard_normal((n, S, D)).astype("float32"))
+    xd = x.to(DEV).requires_grad_(True)
+    y = att(xd, m.to(DEV))
+    (y * w.to(DEV)).sum().backward()
+    osd = oracle_sd(sd)
+    xo = x.clone().requires_grad_(True)
+    yo = O.multi_head_attention(xo, m, osd, h)
+    (yo * w).sum().backward()
+    H.assert_close(y, yo, what="fwd")
+    H.assert_close(xd.grad, xo.grad, GTOL, "dx")
+    assert check_param_grads(att, osd) == 8
+    with torch.no_grad(), hip.knobs(XNRS_MHA_PAIR="0"):
+        y_old = att.eval()(x.to(DEV), m.to(DEV))
+    with torch.no_grad():
+        y_new = att.eval()(x.to(DEV), m.to(DEV))
+    if 1 <= S % 16 <= 4:
+        H.assert_close(y_new, y_old, 2e-6, "tail kernel vs first-generation kernel")
+    else:
+        assert torch.equal(y_new, y_old)

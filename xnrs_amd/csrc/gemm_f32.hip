@@ -756,6 +756,7 @@ static Knobs read_knobs() {
   k.split_min_tiles = num("XNRS_GEMM_SPLIT_MIN_TILES", 512);
   k.mha_lds = (int)num("XNRS_MHA_LDS", -1);
   k.mha_headwave = num("XNRS_MHA_HEADWAVE", 1) != 0;
+  k.mha_pair = num("XNRS_MHA_PAIR", 1) != 0;
   k.mha_bwd_fused = num("XNRS_MHA_BWD_FUSED", 1) != 0;
   k.gemm_dw = (int)num("XNRS_GEMM_DW", 1);
   k.news_fused = (int)num("XNRS_NEWS_FUSED", 1);

@@ -23,6 +23,7 @@ struct Knobs {
   long long split_min_tiles = 512;  // XNRS_GEMM_SPLIT_MIN_TILES: smallest launch the bf16-split kernel takes
   int gemm_dw = 1;              // XNRS_GEMM_DW: 1 = live-row weight gradients on gemm_dw.hip, 2 = every eligible one, 0 = none
   int mha_lds = -1;             // XNRS_MHA_LDS=0|1 force / forbid the LDS-staged attention kernel; -1 = by shape
+  bool mha_pair = true;         // XNRS_MHA_PAIR=0: the first-generation LDS-staged attention kernel instead of mha_core_pair_kernel
   int mha_headwave = 1;         // XNRS_MHA_HEADWAVE=0: generic attention kernel only
   int mha_bwd_fused = 1;        // XNRS_MHA_BWD_FUSED=0: two-kernel attention backward
   int news_fused = 1;           // XNRS_NEWS_FUSED=0|2: never / whenever eligible use the fused short-title news encoder

@@ -468,6 +468,264 @@ static hipError_t launch_lds(const MhaCoreArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// Pair-per-workgroup kernel, second generation (S <= 64, d_k <= 64): the LDS-staged kernel above
+// spent, per wave at S = 50 / d_k = 48, 96 MFMAs (64 x 64 padded scores for 50 x 50) and 633 VALU instructions, the two
+// adding up rather than overlapping (profiles/r01_rocprof_news_encoder_pass.txt: 0.83 ms per 5 240 news against a 0.42 ms
+// matrix floor and a 0.51 ms HBM floor).  Changes:
+//   * TAIL: when S = 16 KTM + rem with rem <= 4 (S = 50: rem 2) the last `rem` keys do not get an MFMA tile of their
+//     own: their rows of K and V are kept row-major in LDS, their scores are 12-FMA dot products against the query
+//     fragments the lane already holds (reduced over the 4 feature groups with two shuffles) and their P.V terms are 4
+//     FMAs per output block.  72 instead of 96 MFMAs per wave at S = 50.
+//   * MFMAs interleave over independent accumulators (key tiles in the first product, output blocks in the second)
+//     instead of running 4-16 deep dependent chains;
+//   * dropout and the key-padding selects are compile-time; every thread stages one FIXED 16-byte column of K and V
+//     (chunk = tid % NCH), so the LDS slot arithmetic is loop-invariant.
+// Arithmetic per element is the one of the kernels above except for the summation order of the tail keys.
+template <int KTM, int NFB, bool TAIL, bool DROP>
+__global__ __launch_bounds__(256) void mha_core_pair_kernel(MhaCoreArgs a) {
+  constexpr int NSLOT = KTM * NFB * 64;
+  constexpr int NCH = NFB * 4;        // 16-byte chunks per padded row
+  constexpr int KP = 256 / NCH;       // keys staged per pass
+  constexpr int NKEYS = KTM * 16 + (TAIL ? 4 : 0);
+  constexpr int NPASS = (NKEYS + KP - 1) / KP;
+  __shared__ __attribute__((aligned(16))) f32x4 Ks[NSLOT];
+  __shared__ __attribute__((aligned(16))) f32x4 Vs[NSLOT];
+  __shared__ __attribute__((aligned(16))) f32x4 Kt[TAIL ? 4 * NCH : 1];  // tail keys, row-major [t][chunk]
+  __shared__ __attribute__((aligned(16))) f32x4 Vt[TAIL ? 4 * NCH : 1];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int qt = tid >> 6;
+  const int pair = blockIdx.x;
+  const int hd = pair % a.n_heads;
+  const int seq = pair / a.n_heads;
+  const int S = a.S, dk = a.d_k;
+  const int ld = (int)a.ld;
+  const int64_t hbase = (int64_t)seq * a.seq_stride + (int64_t)hd * a.head_stride;
+  const float* kbase = a.k + hbase;
+  const float* vbase = a.v + hbase;
+  const int rem = TAIL ? S - KTM * 16 : 0;  // 1..4 (launcher)
+
+  // ---- this wave's query fragments and mask value first: their latency overlaps the staging
+  // unpadded queries (a.q_off): this sequence's live rows are the compact range [q0, q0 + nq) of q / out
+  const int64_t q0 = a.q_off ? a.q_off[seq] : (int64_t)seq * S;
+  const int nq = a.q_off ? (int)(a.q_off[seq + 1] - q0) : S;
+  const int QT = (nq + 15) >> 4;
+  const int c = lane & 15, g = lane >> 4;
+  const int query = qt * 16 + c;
+  const bool qvalid = query < nq;
+  const float* qrow = a.q_off ? a.q + (q0 + (qvalid ? query : 0)) * a.ldq + hd * dk
+                              : a.q + hbase + (int64_t)(qvalid ? query : 0) * ld;
+  f32x4 qf[NFB];
+#pragma unroll
+  for (int fb = 0; fb < NFB; ++fb) {
+    const int f0 = fb * 16 + 4 * g;
+    qf[fb] = (qvalid && f0 < dk) ? *reinterpret_cast<const f32x4*>(qrow + f0) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float mq = 1.f;
+  if (a.mask && !a.q_off && qvalid) {
+    const int64_t mrow = a.mask_gather_ids ? (int64_t)a.mask_gather_ids[seq] * S : (int64_t)seq * S;
+    mq = a.mask[mrow + query];
+  }
+
+  // ---- staging: thread = (chunk ch of the row, key slot ks); keys ks, ks + KP, ...
+  {
+    const int ch = tid % NCH, ks = tid / NCH;
+    const int f0 = ch * 4, b = ch >> 2, g4 = ch & 3;
+    const bool act = ks < KP && f0 < NFB * 16;
+    const bool fok = f0 < dk;
+    f32x4 kv[NPASS], vv[NPASS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int key = ks + ps * KP;
+      kv[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+      vv[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (act && fok && key < S) {
+        kv[ps] = *reinterpret_cast<const f32x4*>(kbase + key * ld + f0);
+        vv[ps] = *reinterpret_cast<const f32x4*>(vbase + key * ld + f0);
+      }
+    }
+    // Slot of fragment (tile t, block b, lane (c, g)) = (t*NFB + b)*64 + g*16 + (c ^ x)  (K: x = 4b + g, V: x = b):
+    // the XOR spreads the chunk-order writes over the banks and keeps every fragment read conflict-free.
+    const int kx = (4 * b + g4) & 15;
+    float* vs = reinterpret_cast<float*>(&Vs[0]);
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int key = ks + ps * KP;
+      if (!act) continue;
+      if (key < KTM * 16) {
+        const int kt = key >> 4, kc = key & 15;
+        // K fragment (kt, fb = b, lane (c = kc, g = g4)) = K[16kt + c][16fb + 4g .. +3]
+        Ks[(kt * NFB + b) * 64 + g4 * 16 + (kc ^ kx)] = kv[ps];
+        // V fragment (kt, dt = b, lane (c = 4*g4 + j, g = kc >> 2)) element r = kc & 3  = V[16kt + 4g + r][16dt + c]
+        float* dst = vs + ((kt * NFB + b) * 64 + (kc >> 2) * 16) * 4 + (kc & 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[((4 * g4 + j) ^ b) * 4] = vv[ps][j];
+      } else if (TAIL && key < KTM * 16 + 4) {
+        const int t = key - KTM * 16;
+        Kt[t * NCH + ch] = kv[ps];
+        Vt[t * NCH + ch] = vv[ps];
+      }
+    }
+  }
+  __syncthreads();
+  if (qt >= QT) return;
+
+  // ---- S^T = K Q^T over the full key tiles
+  f32x4 acc[KTM];
+#pragma unroll
+  for (int kt = 0; kt < KTM; ++kt) acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int fb = 0; fb < NFB; ++fb) {
+    f32x4 kf[KTM];
+#pragma unroll
+    for (int kt = 0; kt < KTM; ++kt) kf[kt] = Ks[(kt * NFB + fb) * 64 + g * 16 + (c ^ ((4 * fb + g) & 15))];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int kt = 0; kt < KTM; ++kt) acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][e], qf[fb][e], acc[kt], 0, 0, 0);
+  }
+  // tail keys: dot products against the query fragment (features 16fb + 4g .. +3 of query c in this lane)
+  float st[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  if constexpr (TAIL) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t < rem) {
+        float part = 0.f;
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) {
+          const f32x4 kr = Kt[t * NCH + fb * 4 + g];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) part = fmaf(qf[fb][e], kr[e], part);
+        }
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        st[t] = part;
+      }
+    }
+  }
+
+  const float inv_sq = a.scaled ? 1.f / sqrtf((float)dk) : 1.f;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < KTM; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float sv = acc[kt][r] * inv_sq;
+      if (mq == 0.f) sv = -1e9f;
+      if (!TAIL && kt == KTM - 1 && kt * 16 + 4 * g + r >= S) sv = -INFINITY;
+      acc[kt][r] = sv;
+      mx = fmaxf(mx, sv);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  if constexpr (TAIL) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t < rem) {
+        st[t] = (mq == 0.f) ? -1e9f : st[t] * inv_sq;
+        mx = fmaxf(mx, st[t]);
+      }
+    }
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < KTM; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ev = attn_exp(acc[kt][r] - mx);
+      acc[kt][r] = ev;
+      sum += ev;
+    }
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  if constexpr (TAIL) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      st[t] = (t < rem) ? attn_exp(st[t] - mx) : 0.f;
+      sum += st[t];
+    }
+  }
+  if (a.stats && qvalid && g == 0) {
+    float* sp = a.stats + (((int64_t)seq * a.n_heads + hd) * (int64_t)S + query) * 2;
+    sp[0] = mx;
+    sp[1] = sum;
+  }
+  const float inv_sum = 1.f / sum;
+  const float keep = 1.f - a.dropout_p;
+  auto drop = [&](float p, int key) {
+    if constexpr (DROP) {
+      const uint64_t idx = ((uint64_t)((int64_t)seq * a.n_heads + hd) * S + (uint64_t)query) * S + (uint64_t)key;
+      return (uniform01(a.seed, idx) < keep) ? p / keep : 0.f;
+    } else {
+      return p;
+    }
+  };
+#pragma unroll
+  for (int kt = 0; kt < KTM; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[kt][r] = drop(acc[kt][r] * inv_sum, kt * 16 + 4 * g + r);
+  if constexpr (TAIL) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) st[t] = drop(st[t] * inv_sum, KTM * 16 + t);
+  }
+
+  // ---- O^T = V^T P^T
+  f32x4 o[NFB];
+#pragma unroll
+  for (int dt = 0; dt < NFB; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < KTM; ++kt) {
+    f32x4 vf[NFB];
+#pragma unroll
+    for (int dt = 0; dt < NFB; ++dt) vf[dt] = Vs[(kt * NFB + dt) * 64 + g * 16 + (c ^ dt)];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int dt = 0; dt < NFB; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[dt][r], acc[kt][r], o[dt], 0, 0, 0);
+  }
+  if constexpr (TAIL) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t < rem) {
+#pragma unroll
+        for (int dt = 0; dt < NFB; ++dt) {
+          const f32x4 vr = Vt[t * NCH + dt * 4 + g];  // V[16 KTM + t][16dt + 4g .. +3] = output rows dv of this lane
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[dt][r] = fmaf(st[t], vr[r], o[dt][r]);
+        }
+      }
+    }
+  }
+  const int hoff = hd * dk;
+  float* orow = a.out + (q0 + query) * a.ldo + hoff;
+#pragma unroll
+  for (int dt = 0; dt < NFB; ++dt) {
+    const int dv0 = dt * 16 + 4 * g;
+    if (qvalid && dv0 < dk) *reinterpret_cast<f32x4*>(orow + dv0) = o[dt];
+  }
+}
+
+template <int KTM, int NFB, bool TAIL>
+static hipError_t launch_pair_nfb(const MhaCoreArgs& a, hipStream_t stream) {
+  const int64_t n_pairs = a.n_seq * a.n_heads;
+  if (n_pairs > 0x7fffffffLL) return hipErrorInvalidValue;
+  if (a.dropout_p > 0.f)
+    hipLaunchKernelGGL((mha_core_pair_kernel<KTM, NFB, TAIL, true>), dim3((unsigned)n_pairs), dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL((mha_core_pair_kernel<KTM, NFB, TAIL, false>), dim3((unsigned)n_pairs), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+template <int KTM, bool TAIL>
+static hipError_t launch_pair(const MhaCoreArgs& a, hipStream_t stream) {
+  switch ((a.d_k + 15) / 16) {
+    case 1: return launch_pair_nfb<KTM, 1, TAIL>(a, stream);
+    case 2: return launch_pair_nfb<KTM, 2, TAIL>(a, stream);
+    case 3: return launch_pair_nfb<KTM, 3, TAIL>(a, stream);
+    default: return launch_pair_nfb<KTM, 4, TAIL>(a, stream);
+  }
+}
+
 template <int KT, int QTP>
 static hipError_t launch_lds_kt(const MhaCoreArgs& a, hipStream_t stream) {
   switch ((a.d_k + 15) / 16) {
@@ -504,6 +762,16 @@ hipError_t launch_mha_core(const MhaCoreArgs& a, hipStream_t stream) {
   // at S=50); one or two tiles: head-per-wave kernel (0.17 vs 0.21 ms at S=30).  XNRS_MHA_LDS=0|1 forces one.
   const bool use_lds = a.q_off ? true : (knobs().mha_lds >= 0 ? knobs().mha_lds != 0 : (KT >= 3));
   if (a.q_off && (!fast || a.stats || a.dropout_p > 0.f || a.ldq % 4 != 0)) return hipErrorInvalidValue;
+  if (fast && use_lds && knobs().mha_pair && (int64_t)a.n_seq * a.S < (1ll << 31)) {
+    // full key tiles through the MFMAs, a remainder of 1..4 keys through the VALU
+    const int rem = a.S & 15;
+    const bool tail = a.S > 16 && rem >= 1 && rem <= 4;
+    const int KTM = tail ? a.S >> 4 : KT;
+    if (tail && KTM == 2) return launch_pair<2, true>(a, stream);
+    if (tail && KTM == 3) return launch_pair<3, true>(a, stream);
+    if (!tail && KTM == 3) return launch_pair<3, false>(a, stream);
+    if (!tail && KTM == 4) return launch_pair<4, false>(a, stream);
+  }
   if (fast && use_lds) {
     switch (KT) {
       case 1: return launch_lds_kt<1, 1>(a, stream);
