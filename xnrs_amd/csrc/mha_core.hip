@@ -481,6 +481,14 @@ static hipError_t launch_lds(const MhaCoreArgs& a, hipStream_t stream) {
 //   * dropout and the key-padding selects are compile-time; every thread stages one FIXED 16-byte column of K and V
 //     (chunk = tid % NCH), so the LDS slot arithmetic is loop-invariant.
 // Arithmetic per element is the one of the kernels above except for the summation order of the tail keys.
+// Measured (tools/bench_stages.py, 5 240 news of 50 x 768, 16 heads): 0.83 ms first generation -> 0.70 ms -> 0.65 ms with
+// the XCD-contiguous pair order = 4.9 TB/s of Q/K/V in + O out.  Counters of this kernel (profiles/r02_attention_core_pmc.txt):
+// 576 VALU + 72 MFMA instructions per wave (2 304 cycles of each pipe: ~42 % busy each), 61 % of HBM peak, a wave alive
+// ~11 us for ~2 us of issue: no single bound left, the rest is latency at the 8-waves-per-SIMD cap.  Tried and dropped: a
+// PERSISTENT variant (grid = 4 workgroups per CU walking XCD-contiguous pair ranges, the next pair's K / V / Q chunks
+// prefetched into registers during the products: 124 VGPRs -> 4 waves per SIMD) measured 0.80 ms -- with the global latency
+// hidden inside the wave, the MFMA / VALU / LDS latencies of its serial instruction stream had half as many waves to
+// hide behind.
 template <int KTM, int NFB, bool TAIL, bool DROP>
 __global__ __launch_bounds__(256) void mha_core_pair_kernel(MhaCoreArgs a) {
   constexpr int NSLOT = KTM * NFB * 64;
@@ -495,7 +503,14 @@ __global__ __launch_bounds__(256) void mha_core_pair_kernel(MhaCoreArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int qt = tid >> 6;
-  const int pair = blockIdx.x;
+  // XCD-contiguous pair order: workgroup L runs on XCD L % 8; handing XCD x the contiguous range of pairs its workgroups
+  // number keeps the heads of one sequence on one XCD, next to each other in time -- a head row is 4 d_k bytes (192 B at
+  // d_k = 48), so neighbouring heads share 128-B lines that would otherwise be fetched by two L2s (0.70 -> 0.65 ms)
+  int pair;
+  {
+    const int L = blockIdx.x, W = gridDim.x, x = L & 7, per = W >> 3, rm = W & 7;
+    pair = per * x + (x < rm ? x : rm) + (L >> 3);
+  }
   const int hd = pair % a.n_heads;
   const int seq = pair / a.n_heads;
   const int S = a.S, dk = a.d_k;
