@@ -4,6 +4,7 @@
     python tools/refresh_profiles.py <tag> [round-prefix, default r01]
 """
 import csv
+import datetime
 import glob
 import io
 import json
@@ -14,6 +15,8 @@ from contextlib import redirect_stdout
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+import subprocess  # noqa: E402
+
 import trace_summary  # noqa: E402
 
 tag = sys.argv[1]
@@ -59,10 +62,20 @@ fetch, write = counter("fetch", "FETCH_SIZE"), counter("write", "WRITE_SIZE")
 hit, req = counter("tcc", "TCC_HIT_sum"), counter("tcc", "TCC_REQ_sum")
 rows_, D = 65500, 768
 alg = rows_ * D * 4 + 3 * D * D * 4 + rows_ * 3 * D * 4
+commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+dirty = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "xnrs_amd/csrc"], capture_output=True, text=True).stdout.strip())
+# gather-only kernel (xnrs_gather_rows, 28 160 uniform ids into the 65 536-news table): profiles/r02_gather_rocprof.txt
+gather_fetch_kb, gather_write_kb = 2.1121e6, 4.2241e6
 json.dump({
+    "commit": commit + ("+uncommitted csrc changes" if dirty else ""),
+    "date": datetime.date.today().isoformat(),
+    "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes with --kernel-trace only; bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB)",
+    "gather_rows_hbm_bytes_per_launch": int((2 * gather_fetch_kb + gather_write_kb) * 1024),
+    "gather_note": "gather_rows_kernel<true>, 28 160 uniform ids x 153 600-B news rows out of a 10-GB table: FETCH_SIZE 2.1121e6 KB (x2), "
+                   "WRITE_SIZE 4.2241e6 KB = 8.65 GB = 1.00x of read + write (profiles/r02_gather_rocprof.txt, tools/gpu_gather.sh)",
     "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), tools/gpu_profile.sh {tag}, MI355X; "
               f"see profiles/{rnd}_rocprof_news_encoder_pass.txt",
-    "kernel": "gemm_f32_kernel<2,2,false,false,true,5,16,true,4> grid 2359296 (fused Q/K/V projection of one 65 500-row pass)",
+    "kernel": "gemm_f32_kernel<2,2,false,false,true,5,16,true,4,false,2> grid 2359296 (fused Q/K/V projection of one 65 500-row pass)",
     "FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB": write,
     "correction": "gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of 16-B-per-lane coalesced loads (MI355X_MICROARCH.md, HBM): "
                   "reads doubled; WRITE_SIZE taken as is.  Cross-check: TCC_MISS_sum x 128 B = 2 x FETCH + WRITE within 2 %.",
