@@ -481,16 +481,17 @@ static hipError_t launch_lds(const MhaCoreArgs& a, hipStream_t stream) {
 //   * dropout and the key-padding selects are compile-time; every thread stages one FIXED 16-byte column of K and V
 //     (chunk = tid % NCH), so the LDS slot arithmetic is loop-invariant.
 // Arithmetic per element is the one of the kernels above except for the summation order of the tail keys.
-// Measured (tools/bench_stages.py, 5 240 news of 50 x 768, 16 heads): 0.83 ms first generation -> 0.70 ms -> 0.65 ms with
-// the XCD-contiguous pair order = 4.9 TB/s of Q/K/V in + O out.  Counters of this kernel (profiles/r02_attention_core_pmc.txt):
-// 576 VALU + 72 MFMA instructions per wave (2 304 cycles of each pipe: ~42 % busy each), 61 % of HBM peak, a wave alive
+// Measured (tools/bench_stages.py, 5 240 news of 50 x 768, 16 heads): 0.83 ms first generation -> 0.70 ms -> 0.64 ms with
+// the XCD-contiguous pair order = 5.0 TB/s of Q/K/V in + O out.  Counters of this kernel (profiles/r02_attention_core_pmc.txt):
+// 531 VALU + 72 MFMA instructions per wave (~2 200 cycles of each pipe: ~42 % busy each), 62 % of HBM peak, LDS bank
+// conflicts 2 % of the LDS cycles (10.7 % before V's transpose moved into registers), a wave alive
 // ~11 us for ~2 us of issue: no single bound left, the rest is latency at the 8-waves-per-SIMD cap.  Tried and dropped: a
 // PERSISTENT variant (grid = 4 workgroups per CU walking XCD-contiguous pair ranges, the next pair's K / V / Q chunks
 // prefetched into registers during the products: 124 VGPRs -> 4 waves per SIMD) measured 0.80 ms -- with the global latency
 // hidden inside the wave, the MFMA / VALU / LDS latencies of its serial instruction stream had half as many waves to
 // hide behind.
 template <int KTM, int NFB, bool TAIL, bool DROP>
-__global__ __launch_bounds__(256) void mha_core_pair_kernel(MhaCoreArgs a) {
+__global__ __launch_bounds__(256, (KTM * NFB <= 9 ? 8 : 5)) void mha_core_pair_kernel(MhaCoreArgs a) {
   constexpr int NSLOT = KTM * NFB * 64;
   constexpr int NCH = NFB * 4;        // 16-byte chunks per padded row
   constexpr int KP = 256 / NCH;       // keys staged per pass
@@ -542,27 +543,35 @@ __global__ __launch_bounds__(256) void mha_core_pair_kernel(MhaCoreArgs a) {
     mq = a.mask[mrow + query];
   }
 
-  // ---- staging: thread = (chunk ch of the row, key slot ks); keys ks, ks + KP, ...
+  // ---- staging.  K: thread = (chunk ch of the row, key slot ks), keys ks, ks + KP, ...; one ds_write_b128 per chunk.
+  // V: thread = (chunk vch, group vkg of FOUR consecutive keys); the 4 x 4 block is transposed in registers and its four
+  // columns go out as four ds_write_b128 (the first version scattered 16 ds_write_b32 per block with a 2-way bank
+  // conflict on every one: 10.7 % of the LDS cycles).  Slot of fragment (tile t, block b, lane (c, g)) =
+  // (t*NFB + b)*64 + g*16 + swizzle(c): K: c ^ (4b + g); V: c ^ ((c >> 3) | ((b & 1) << 1)) -- bijections of the 16
+  // slots of a (tile, block, g) group, so every fragment read stays a conflict-free ds_read_b128, chosen so that the 8
+  // contiguous lanes of a store group (chunks of one or two feature blocks) hit 8 distinct 16-byte bank groups.
   {
     const int ch = tid % NCH, ks = tid / NCH;
     const int f0 = ch * 4, b = ch >> 2, g4 = ch & 3;
-    const bool act = ks < KP && f0 < NFB * 16;
+    const bool act = ks < KP;
     const bool fok = f0 < dk;
-    f32x4 kv[NPASS], vv[NPASS];
+    const int vch = tid & 15, vkg = tid >> 4;  // V: 16 lanes per key group, the first NCH of them active
+    const int vf0 = vch * 4, vb = vch >> 2, vg4 = vch & 3;
+    const bool vact = vch < NCH && vkg < KTM * 4 + (TAIL ? 1 : 0);
+    f32x4 kv[NPASS], vv[4];
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       const int key = ks + ps * KP;
       kv[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
-      vv[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (act && fok && key < S) {
-        kv[ps] = *reinterpret_cast<const f32x4*>(kbase + key * ld + f0);
-        vv[ps] = *reinterpret_cast<const f32x4*>(vbase + key * ld + f0);
-      }
+      if (act && fok && key < S) kv[ps] = *reinterpret_cast<const f32x4*>(kbase + key * ld + f0);
     }
-    // Slot of fragment (tile t, block b, lane (c, g)) = (t*NFB + b)*64 + g*16 + (c ^ x)  (K: x = 4b + g, V: x = b):
-    // the XOR spreads the chunk-order writes over the banks and keeps every fragment read conflict-free.
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = 4 * vkg + r;
+      vv[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (vact && vf0 < dk && key < S) vv[r] = *reinterpret_cast<const f32x4*>(vbase + key * ld + vf0);
+    }
     const int kx = (4 * b + g4) & 15;
-    float* vs = reinterpret_cast<float*>(&Vs[0]);
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       const int key = ks + ps * KP;
@@ -571,14 +580,22 @@ __global__ __launch_bounds__(256) void mha_core_pair_kernel(MhaCoreArgs a) {
         const int kt = key >> 4, kc = key & 15;
         // K fragment (kt, fb = b, lane (c = kc, g = g4)) = K[16kt + c][16fb + 4g .. +3]
         Ks[(kt * NFB + b) * 64 + g4 * 16 + (kc ^ kx)] = kv[ps];
-        // V fragment (kt, dt = b, lane (c = 4*g4 + j, g = kc >> 2)) element r = kc & 3  = V[16kt + 4g + r][16dt + c]
-        float* dst = vs + ((kt * NFB + b) * 64 + (kc >> 2) * 16) * 4 + (kc & 3);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dst[((4 * g4 + j) ^ b) * 4] = vv[ps][j];
       } else if (TAIL && key < KTM * 16 + 4) {
-        const int t = key - KTM * 16;
-        Kt[t * NCH + ch] = kv[ps];
-        Vt[t * NCH + ch] = vv[ps];
+        Kt[(key - KTM * 16) * NCH + ch] = kv[ps];
+      }
+    }
+    if (vact) {
+      if (vkg < KTM * 4) {
+        // V fragment (kt, dt = vb, lane (c = 4*vg4 + j, g = vkg & 3)) elements r = 0..3 = V[16kt + 4g + r][16dt + c]
+        const int base = ((vkg >> 2) * NFB + vb) * 64 + (vkg & 3) * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c4 = 4 * vg4 + j;
+          Vs[base + (c4 ^ ((c4 >> 3) | ((vb & 1) << 1)))] = f32x4{vv[0][j], vv[1][j], vv[2][j], vv[3][j]};
+        }
+      } else if (TAIL) {  // the key group behind the full tiles: the tail keys, row-major
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Vt[r * NCH + vch] = vv[r];
       }
     }
   }
@@ -692,7 +709,7 @@ __global__ __launch_bounds__(256) void mha_core_pair_kernel(MhaCoreArgs a) {
   for (int kt = 0; kt < KTM; ++kt) {
     f32x4 vf[NFB];
 #pragma unroll
-    for (int dt = 0; dt < NFB; ++dt) vf[dt] = Vs[(kt * NFB + dt) * 64 + g * 16 + (c ^ dt)];
+    for (int dt = 0; dt < NFB; ++dt) vf[dt] = Vs[(kt * NFB + dt) * 64 + g * 16 + (c ^ ((c >> 3) | ((dt & 1) << 1)))];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
