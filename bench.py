@@ -54,19 +54,26 @@ class Cfg(dict):
     __getattr__ = dict.__getitem__
 
 
-def news_flops(S, D, A, E, att=True, head=True):
-    """algorithmic FLOPs per news item."""
+def news_flops(S, D, A, E, att=True, head=True, folded=False):
+    """algorithmic FLOPs per news item.  folded=True: what the library EXECUTES in inference when
+    the out-projection is folded behind the pooling: the S x D x D out-projection becomes one
+    D x D product per news (the A x D x D folded weight is per call, not per news)."""
     f = 2 * S * D * A + 2 * S * A + 2 * S * D
     if att:
-        f += 8 * S * D * D + 4 * S * S * D
+        f += (6 * S * D * D + 2 * D * D if folded else 8 * S * D * D) + 4 * S * S * D
     if head:
         f += 2 * D * E + 2 * E * E
     return f
 
 
-def impression_flops(w):
-    n = (w["H"] + w["C"]) * news_flops(w["S"], w["D"], w["A"], w["E"])
-    u = 8 * w["H"] * w["E"] ** 2 + 4 * w["H"] ** 2 * w["E"] + 2 * w["H"] * w["E"] * w["A"] + 2 * w["H"] * w["A"] + 2 * w["H"] * w["E"]
+def fold_on():
+    return os.environ.get("XNRS_FOLD_OUT", "1") != "0"
+
+
+def impression_flops(w, folded=False):
+    n = (w["H"] + w["C"]) * news_flops(w["S"], w["D"], w["A"], w["E"], folded=folded)
+    proj = (6 * w["H"] + 2) if folded else 8 * w["H"]
+    u = proj * w["E"] ** 2 + 4 * w["H"] ** 2 * w["E"] + 2 * w["H"] * w["E"] * w["A"] + 2 * w["H"] * w["A"] + 2 * w["H"] * w["E"]
     return n + u + 2 * w["C"] * w["E"]
 
 
@@ -265,7 +272,9 @@ def news_only_extra(device, steps=20, warmup=10):
             fn()
             torch.cuda.synchronize()
         dt = timed(fn, steps, warmup, False) / steps
-        fl = 1024 * news_flops(S, D, 256, w["E"])
+        # executed FLOPs: the <= 32-token shapes run the single fused kernel (full out-projection in the kernel), the
+        # 50 x 768 shape the pipeline with the out-projection folded behind the pooling
+        fl = 1024 * news_flops(S, D, 256, w["E"], folded=fold_on() and S > 32)
         out[name] = dict(news_per_s=1024 / dt, ms=dt * 1e3, tflops=fl / dt / 1e12,
                          frac_fp32_mfma=fl / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                          alg_gbs=1024 * (4 * S * D + 4 * S + 4 * w["E"] + 4) / dt / 1e9)
@@ -514,6 +523,18 @@ def gemm_modes_extra(model, hist, cand, steps, scores_f32, cpu_sample):
     return out
 
 
+def unfolded_extra(model, hist, cand, steps, scores):
+    """The same step with the reference's operation order (per-token out-projection, XNRS_FOLD_OUT=0): what the folded
+    out-projection buys, and how far the two score sets are apart."""
+    with hip.knobs(XNRS_FOLD_OUT="0"):
+        fn = lambda: step(model, hist, cand)  # noqa: E731
+        dt = timed(fn, steps, 2, False)
+        r = fn()
+    B = hist[0].shape[0]
+    return dict(impressions_per_s=B * steps / dt, ms_per_step=dt / steps * 1e3,
+                max_rel_diff_vs_folded=((r - scores).abs().max() / scores.abs().max()).item())
+
+
 def padding_free_extra(model, hist, cand, steps, scores_dense):
     """The same step without the padding work (both exact, both data-dependent, hence not the headline):
       skip_empty : all-masked news -- the empty history slots, 49 % of this synthetic workload's history
@@ -747,8 +768,14 @@ def main():
                          "alg_tflops": ach,
                          "launches_timed": q_n, "avg_launch_ms": q_ms / max(q_n, 1),
                          "alg_flops_per_launch": q_fl / max(q_n, 1)},
-            "whole_path": {"alg_tflops": impression_flops(w) * value / n_gpus / 1e12,
-                           "frac_fp32_mfma": impression_flops(w) * value / n_gpus / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+            # executed FLOPs (out-projection folded behind the pooling unless XNRS_FOLD_OUT=0); `reference_order_tflops` prices
+            # the same impressions at the FLOPs of the reference's operation order -- it is NOT a utilisation figure
+            "whole_path": {"alg_tflops": impression_flops(w, fold_on()) * value / n_gpus / 1e12,
+                           "frac_fp32_mfma": impression_flops(w, fold_on()) * value / n_gpus / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                           "out_projection": ("folded behind the pooling: fc1 on the attention rows with W1.Wo, one Wo product "
+                                              "per news after the weighted sum (exact algebra, DESIGN.md section 4.6)"
+                                              if fold_on() else "per token row (XNRS_FOLD_OUT=0)"),
+                           "reference_order_tflops": impression_flops(w) * value / n_gpus / 1e12,
                            "alg_gbs": impression_bytes(w) * value / n_gpus / 1e9,
                            "frac_hbm": impression_bytes(w) * value / n_gpus / 1e9 / HBM_PEAK_GBS},
         }
@@ -802,6 +829,8 @@ def main():
                 out["extra"]["latency_one_impression"] = latency_extra(device)
                 out["extra"]["id_path_B512"] = id_path_extra(device)
                 out["extra"]["padding_free"] = padding_free_extra(model, hist, cand, args.steps, scores)
+                if fold_on():
+                    out["extra"]["per_token_out_projection"] = unfolded_extra(model, hist, cand, args.steps, scores)
                 if args.gemm_mode == 0:
                     out["extra"]["gemm_modes"] = gemm_modes_extra(model, hist, cand, args.steps, scores, cpu_sample)
             out["extra"]["nrms_train_step_B64"] = train_step_extra(device)

@@ -393,3 +393,57 @@ def test_naml_with_padding_free_encoders_matches_golden():
         ue = model.get_user_embeddings(batch)
     H.assert_close(r, g[f"{name}/r"], what=name + " scores")
     H.assert_close(ue, g[f"{name}/ue"], what=name + " ue")
+
+
+@pytest.mark.parametrize("S,D,h,A,bias,with_ids", [(50, 64, 4, 48, True, False), (40, 96, 3, 80, False, False),
+                                                   (33, 128, 8, 256, True, True), (7, 20, 5, 16, True, False),
+                                                   (64, 32, 2, 100, False, True)])
+def test_folded_out_projection_matches_per_token_out_projection(S, D, h, A, bias, with_ids):
+    """Inference folds the attention out-projection behind the pooling (api.hip "fold": fc1 on the O rows with W1.Wo, one
+    Wo product per news after the weighted sum, bias times the sum of the weights) -- exact algebra for every input, a
+    different rounding order.  Against the per-token out-projection (XNRS_FOLD_OUT=0, the reference's order) and the
+    oracle: news vectors, news mask, with and without biases, the id-gather path, an all-masked and a fully live news,
+    masks with holes; and the pooling WEIGHTS of the user tower (return_weights) under both orders."""
+    from xnrs_amd import hip
+    enc, sd = load(news_encoding.TextEncoder(pooler=layers.AdditiveAttention(D, A), p_dropout=0.0, out_features=24,
+                                             in_features=D, att=layers.MultiHeadAttention(h, D), bias=bias), 501)
+    rng = synth.rng_for(502 + S)
+    n = 37
+    x = torch.from_numpy(rng.standard_normal((n, S, D)).astype("float32"))
+    m = torch.from_numpy((rng.random((n, S)) < 0.7).astype("float32"))
+    m[0] = 0
+    m[1] = 1
+    ids = torch.from_numpy(rng.integers(0, n, size=(50,)).astype("int64")) if with_ids else None
+
+    def run():
+        with torch.no_grad():
+            if with_ids:
+                y, hm = enc.forward_ids(x.to(DEV), m.to(DEV), ids.to(DEV).reshape(1, -1))
+            else:
+                y, hm = enc((x.to(DEV).unsqueeze(0), m.to(DEV).reshape(1, n, S, 1)))
+        return y[0], hm[0]
+
+    y1, hm1 = run()
+    with hip.knobs(XNRS_FOLD_OUT="0"):
+        y0, hm0 = run()
+    assert torch.equal(hm0, hm1)
+    H.assert_close(y1, y0, 2e-5, "folded vs per-token out-projection")
+    assert not torch.equal(y1, y0) or D < 32  # (the two orders really are different computations)
+    xo, mo = (x[ids], m[ids]) if with_ids else (x, m)
+    yo, hmo = O.text_encoder(xo.unsqueeze(0), mo.reshape(1, -1, S, 1), sd, h)
+    H.assert_close(y1, yo[0], what="folded vs oracle")
+    assert torch.equal(hm1.cpu(), hmo[0])
+
+    ue, usd = load(user_encoding.UserEncoder(pooler=layers.AdditiveAttention(D, A), p_dropout=0.0, emb_dim=D,
+                                             att=layers.MultiHeadAttention(h, D), bias=bias), 503)
+    hx = torch.from_numpy(rng.standard_normal((5, S, D)).astype("float32"))
+    hmask = torch.from_numpy((rng.random((5, S, 1)) < 0.7).astype("float32"))
+    with torch.no_grad():
+        u1, a1 = ue((hx.to(DEV), hmask.to(DEV)), return_weights=True)
+        with hip.knobs(XNRS_FOLD_OUT="0"):
+            u0, a0 = ue((hx.to(DEV), hmask.to(DEV)), return_weights=True)
+    H.assert_close(u1, u0, 2e-5, "user vector, folded vs per-token")
+    H.assert_close(a1, a0, 2e-5, "pooling weights, folded vs per-token")
+    uo, ao = O.user_encoder(hx, hmask, usd, h, return_weights=True)
+    H.assert_close(u1, uo, what="user vector vs oracle")
+    H.assert_close(a1, ao, what="pooling weights vs oracle")

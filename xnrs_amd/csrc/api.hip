@@ -33,6 +33,7 @@ struct Plan {
   size_t off_stats, off_a;  // training only: softmax row statistics, pooling weights
   size_t off_planes;        // bf16-split GEMM modes: pre-split weight planes (wq, wk, wv, wo, w1)
   size_t off_nf;            // fused short-sequence encoder: fragment-ordered weight images
+  size_t off_fw, off_fb, off_po, off_as;  // folded out-projection (inference): W1.Wo, W1.bo + b1, pooled O rows, sum of weights
   size_t total;
 };
 
@@ -76,6 +77,12 @@ Plan make_plan(int64_t n_seq, int L, int D, int A, int E, bool att, bool additiv
     else if (news_fused_plan(L, D, n_heads, A, &nf)) nfb = nf.img_bytes;
   }
   p.off_nf = nfb ? take((nfb + 3) / 4) : 0;
+  // folded out-projection (seq_encode "fold"): reserved whenever the shape is eligible, whatever the knob says
+  const bool foldable = att && additive && !train;
+  p.off_fw = foldable ? take((size_t)A * D) : 0;
+  p.off_fb = foldable ? take((size_t)A) : 0;
+  p.off_po = foldable ? take((size_t)n_seq * D) : 0;
+  p.off_as = foldable ? take((size_t)n_seq) : 0;
   p.total = off;
   return p;
 }
@@ -147,6 +154,36 @@ GemmArgs gemm1(const float* A, const int32_t* ids, int gS, int64_t lda, const fl
   return g;
 }
 
+// ---- "fold": the out-projection behind the pooling (inference).
+// The pooler never needs the attention OUTPUT rows Y_i = Wo O_i + bo one by one (layers.py:154 -> layers.py:60-65):
+//   fc1(Y_i)           = W1 (Wo O_i + bo) + b1 = (W1 Wo) O_i + (W1 bo + b1)            -> scores straight from the O rows
+//   sum_i a_i Y_i      = Wo (sum_i a_i O_i) + bo (sum_i a_i)                             -> ONE out-projection per sequence
+// so the rows x D x D out-projection GEMM (12.4 of 57 ms of the benchmark step) becomes an n_seq x D x D one, plus an
+// A x D x D product for the folded weight per call (0.3 GFLOP; the ABI keeps no state between calls).  Exact algebra for
+// every input -- only the rounding order differs from the reference's (observed <= 2e-6 on the scores, bar 1e-4); the
+// training forward keeps Y (the backward needs it).  XNRS_FOLD_OUT=0 keeps the per-token out-projection.
+// Returns the fc1 bias to use (nullptr if there is none).
+const float* fold_out_projection(const xnrs_mha_params* att, const xnrs_additive_params* pool, int D, int A, float* wf,
+                                 float* bf, hipStream_t stream, hipError_t* err) {
+  GemmArgs g{};  // wf[A][D] = W1[A][D] . Wo[D][D]   (B k-major: its row index is the contraction index)
+  g.A = pool->w1;
+  g.lda = D;
+  g.W[0] = att->wo;
+  g.b_kn = 1;
+  g.ldw = D;
+  g.nseg = 1;
+  g.Nseg = D;
+  g.C = wf;
+  g.ldc = D;
+  g.M = A;
+  g.K = D;
+  *err = launch_gemm_f32(g, stream);
+  if (*err != hipSuccess || !att->bo) return pool->b1;
+  // bf[1][A] = bo[1][D] . W1[A][D]^T + b1
+  *err = launch_gemm_f32(gemm1(att->bo, nullptr, 0, D, pool->w1, pool->b1, bf, A, 1, A, D, XNRS_ACT_NONE), stream);
+  return bf;
+}
+
 // x:(n_seq,L,D) [or table + ids], m:(n_seq,L) [or table mask] -> y
 //   pooled == false: y:(n_seq,L,D) = att(x)            (MultiHeadAttention alone)
 //   pooled == true : y:(n_seq,E')  = head(pool(att(x)))
@@ -197,6 +234,24 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
                     !(ids && !live_src_rows);
   const int32_t* lvx = live ? (ids ? live_src_rows : live_rows) : nullptr;  // rows of x (table rows with ids)
 
+  // Short sequences go through the fused kernel (below); everything else folds the out-projection behind the pooling
+  const bool fused = att && additive && !train && !a_out && att->dropout_p == 0.f && gemm_mode() == 0 &&
+                     knobs().news_fused && news_fused_plan(L, D, att->n_heads, A, nullptr) &&
+                     (D / att->n_heads) * att->n_heads == D && (knobs().news_fused == 2 || (L >= 26 && n_seq >= 192));
+  const bool fold = att && additive && !train && !fused && knobs().fold_out;
+  float* wf = reinterpret_cast<float*>(w + p.off_fw);
+  float* bf = reinterpret_cast<float*>(w + p.off_fb);
+  float* pob = reinterpret_cast<float*>(w + p.off_po);
+  float* asum = reinterpret_cast<float*>(w + p.off_as);
+  const float* fc1_w = additive ? pool->w1 : nullptr;
+  const float* fc1_b = additive ? pool->b1 : nullptr;
+  if (fold) {
+    hipError_t fe = hipSuccess;
+    fc1_b = fold_out_projection(att, pool, D, A, wf, bf, stream, &fe);
+    XNRS_TRY(fe);
+    fc1_w = wf;
+  }
+
   // bf16-split GEMM modes: split the weights ONCE per call (the chunk loop below reuses them ~20 times per step)
   const unsigned short *pq = nullptr, *pk = nullptr, *pv = nullptr, *po = nullptr, *p1 = nullptr;
   if (gemm_mode() != 0) {
@@ -212,7 +267,7 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
       pv = prep(att->wv, D, D);
       po = prep(att->wo, D, D);
     }
-    if (pooled && additive) p1 = prep(pool->w1, A, D);
+    if (pooled && additive) p1 = prep(fc1_w, A, D);
   }
 
   // Short sequences: attention + additive pooling of ALL sequences in one launch (news_fused.hip); only the pooled
@@ -223,9 +278,6 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
   // with 1 news per workgroup (twice the workgroups, two per CU) from ~200: 1024 x 30 tokens: 326 vs 374 us for the
   // six-launch pipeline, 28 160 x 30: 8.2 vs 9.0 ms, 256 x 30: 116 vs 151 us; 64 x 30: 112 vs 94 us, 1024 x 20: 319 vs
   // 271 us.  XNRS_NEWS_FUSED=2 forces it for every eligible shape (tests), 0 turns it off.
-  const bool fused = att && additive && !train && !a_out && att->dropout_p == 0.f && gemm_mode() == 0 &&
-                     knobs().news_fused && news_fused_plan(L, D, att->n_heads, A, nullptr) &&
-                     (D / att->n_heads) * att->n_heads == D && (knobs().news_fused == 2 || (L >= 26 && n_seq >= 192));
   if (fused) {
     NewsFusedArgs f{};
     f.x = x; f.ids = ids; f.mask = m;
@@ -320,7 +372,9 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
       }
 
       float* dst = pooled ? yb : y + c0 * (int64_t)L * D;
-      if (live) {
+      if (fold) {
+        dst = o;  // the pooler works on the O rows (fold_out_projection)
+      } else if (live) {
         ProfScope ps(2, 2.0 * n_live * (double)D * D, stream);
         XNRS_TRY(hipMemsetAsync(dst, 0, (size_t)rows * D * sizeof(float), stream));
         if (n_live > 0) {
@@ -350,7 +404,7 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
         }
       } else {
         ProfScope ps(3, 2.0 * rows * (double)D * A, stream);
-        XNRS_TRY(launch_gemm_f32(gemm1(seq, seq_ids, L, D, pool->w1, pool->b1, t, A, rows, A, D, XNRS_ACT_TANH, p1), stream));
+        XNRS_TRY(launch_gemm_f32(gemm1(seq, seq_ids, L, D, fc1_w, fc1_b, t, A, rows, A, D, XNRS_ACT_TANH, p1), stream));
       }
       AdditivePoolArgs pa{};
       pa.t = t;
@@ -361,7 +415,8 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
       pa.x_gather_ids = seq_ids;
       pa.x = seq;
       pa.ldx = D;
-      pa.y = pooled_dst;
+      pa.y = fold ? pob + c0 * (int64_t)D : pooled_dst;
+      pa.asum_out = fold ? asum + c0 : nullptr;
       pa.a_out = a_save ? a_save : (a_out ? a_out + c0 * (int64_t)L : nullptr);
       pa.hm_out = cm ? hm_dst : nullptr;
       pa.n_seq = nc;
@@ -391,6 +446,12 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
         XNRS_TRY(launch_mean_pool(mp, stream));
       }
     }
+  }
+  if (fold) {  // pooled = Wo (sum_i a_i O_i) + bo (sum_i a_i): one out-projection per sequence
+    float* dst = head ? pb : y;
+    ProfScope ps(2, 2.0 * n_seq * (double)D * D, stream);
+    XNRS_TRY(launch_gemm_f32(gemm1(pob, nullptr, 0, D, att->wo, nullptr, dst, D, n_seq, D, D, XNRS_ACT_NONE, po), stream));
+    if (att->bo) XNRS_TRY(launch_add_rowscaled_bias(dst, D, asum, att->bo, n_seq, D, stream));
   }
   if (pooled && head) {
     ProfScope ps(5, 2.0 * n_seq * ((double)D * E + (double)E * E), stream);
@@ -475,7 +536,7 @@ int32_t xnrs_text_encoder_fwd(const float* x, const float* m, const int32_t* ids
 // ---- unpadded news encoder (inference): workspace carve, every region 256-B aligned
 namespace {
 struct UnpadPlan {
-  size_t off_kv, off_q, off_o, off_y, off_t, off_p, off_h, total;
+  size_t off_kv, off_q, off_o, off_y, off_t, off_p, off_h, off_fw, off_fb, off_po, off_as, total;
 };
 UnpadPlan make_unpad_plan(int64_t n_news, int64_t n_valid, int S, int D, int A, int E, bool att, bool head) {
   UnpadPlan p{};
@@ -493,6 +554,10 @@ UnpadPlan make_unpad_plan(int64_t n_news, int64_t n_valid, int S, int D, int A, 
   p.off_t = take(nv * A);
   p.off_p = head ? take((size_t)n_news * D) : 0;
   p.off_h = head ? take((size_t)n_news * E) : 0;
+  p.off_fw = att ? take((size_t)A * D) : 0;  // folded out-projection (seq_encode "fold")
+  p.off_fb = att ? take((size_t)A) : 0;
+  p.off_po = att ? take((size_t)n_news * D) : 0;
+  p.off_as = att ? take((size_t)n_news) : 0;
   p.total = cur;
   return p;
 }
@@ -532,6 +597,20 @@ int32_t xnrs_text_encoder_fwd_unpadded(const float* x, const int32_t* ids, int64
 
   const float* vals = x;          // what the pooler weights: compact y rows, or x rows through `rows`
   const int32_t* val_ids = rows;
+  // the same folded out-projection as the padded path (seq_encode "fold"), so the two stay bitwise equal
+  const bool fold = att && knobs().fold_out;
+  float* wf = reinterpret_cast<float*>(w + p.off_fw);
+  float* bf = reinterpret_cast<float*>(w + p.off_fb);
+  float* pob = reinterpret_cast<float*>(w + p.off_po);
+  float* asum = reinterpret_cast<float*>(w + p.off_as);
+  const float* fc1_w = pool->w1;
+  const float* fc1_b = pool->b1;
+  if (fold) {
+    hipError_t fe = hipSuccess;
+    fc1_b = fold_out_projection(att, pool, D, A, wf, bf, stream, &fe);
+    XNRS_TRY(fe);
+    fc1_w = wf;
+  }
   if (att) {
     const int dk = D / att->n_heads;
     {  // K and V of EVERY token row: padded tokens stay keys (QUERY-row mask, layers.py:142-144)
@@ -576,17 +655,17 @@ int32_t xnrs_text_encoder_fwd_unpadded(const float* x, const int32_t* ids, int64
         ProfScope ps(1, 4.0 * n_valid * (double)S * D, stream);
         XNRS_TRY(launch_mha_core(ma, stream));
       }
-      {
+      if (!fold) {
         ProfScope ps(2, 2.0 * n_valid * (double)D * D, stream);
         XNRS_TRY(launch_gemm_f32(gemm1(oc, nullptr, 0, D, att->wo, att->bo, yc, D, n_valid, D, D, XNRS_ACT_NONE), stream));
       }
     }
-    vals = yc;
+    vals = fold ? oc : yc;
     val_ids = nullptr;
   }
   if (n_valid > 0) {
     ProfScope ps(3, 2.0 * n_valid * (double)D * A, stream);
-    XNRS_TRY(launch_gemm_f32(gemm1(vals, val_ids, 1, D, pool->w1, pool->b1, tc, A, n_valid, A, D, XNRS_ACT_TANH), stream));
+    XNRS_TRY(launch_gemm_f32(gemm1(vals, val_ids, 1, D, fc1_w, fc1_b, tc, A, n_valid, A, D, XNRS_ACT_TANH), stream));
   }
   AdditivePoolArgs pa{};
   pa.t = tc;
@@ -596,7 +675,8 @@ int32_t xnrs_text_encoder_fwd_unpadded(const float* x, const int32_t* ids, int64
   pa.ldx = D;
   pa.row_off = row_off;
   pa.row_ids = val_ids;
-  pa.y = head ? pb : y;
+  pa.y = fold ? pob : (head ? pb : y);
+  pa.asum_out = fold ? asum : nullptr;
   pa.hm_out = hm;
   pa.n_seq = n_news;
   pa.N = S;
@@ -605,6 +685,12 @@ int32_t xnrs_text_encoder_fwd_unpadded(const float* x, const int32_t* ids, int64
   {
     ProfScope ps(4, 2.0 * n_valid * (double)(A + D), stream);
     XNRS_TRY(launch_additive_pool(pa, stream));
+  }
+  if (fold) {
+    float* dst = head ? pb : y;
+    ProfScope ps(2, 2.0 * n_news * (double)D * D, stream);
+    XNRS_TRY(launch_gemm_f32(gemm1(pob, nullptr, 0, D, att->wo, nullptr, dst, D, n_news, D, D, XNRS_ACT_NONE), stream));
+    if (att->bo) XNRS_TRY(launch_add_rowscaled_bias(dst, D, asum, att->bo, n_news, D, stream));
   }
   if (head) {
     ProfScope ps(5, 2.0 * n_news * ((double)D * E + (double)E * E), stream);

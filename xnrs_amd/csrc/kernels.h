@@ -21,6 +21,7 @@ struct Knobs {
   long long gemm_group = -1;    // XNRS_GEMM_GROUP=n column tiles per walk group (0 = plain walk); -1 = automatic
   int gemm_tile = -1;           // XNRS_GEMM_TILE=0..3 force a block tile; -1 = cost model
   long long split_min_tiles = 512;  // XNRS_GEMM_SPLIT_MIN_TILES: smallest launch the bf16-split kernel takes
+  bool fold_out = true;         // XNRS_FOLD_OUT=0: inference keeps the per-token out-projection (api.hip "fold")
   int gemm_dw = 1;              // XNRS_GEMM_DW: 1 = live-row weight gradients on gemm_dw.hip, 2 = every eligible one, 0 = none
   int mha_lds = -1;             // XNRS_MHA_LDS=0|1 force / forbid the LDS-staged attention kernel; -1 = by shape
   bool mha_pair = true;         // XNRS_MHA_PAIR=0: the first-generation LDS-staged attention kernel instead of mha_core_pair_kernel
@@ -220,6 +221,7 @@ struct AdditivePoolArgs {
   float* y;          // [n_seq, D]
   float* a_out;      // [n_seq*N] or null
   float* hm_out;     // [n_seq] or null : clamp(sum mask,0,1)
+  float* asum_out;   // [n_seq] or null : sum_i a_i (1 - 1e-8/denominator, or 0 for an all-masked sequence)
   int64_t n_seq;
   int32_t N, D, A;
   // unpadded rows (nullable): sequence n owns the compact rows row_off[n] .. row_off[n+1] (<= N of them) of t and x
@@ -228,6 +230,8 @@ struct AdditivePoolArgs {
   const int32_t* row_ids;  // nullable, with row_off: value row of compact row j is x[row_ids[j]] (t stays compact)
 };
 hipError_t launch_additive_pool(const AdditivePoolArgs& a, hipStream_t stream);
+// p[n][d] += s[n] * b[d]   (the out-projection bias behind a pooled out-projection, api.hip "fold")
+hipError_t launch_add_rowscaled_bias(float* p, int64_t ld, const float* s, const float* b, int64_t n, int D, hipStream_t stream);
 
 struct MeanPoolArgs {
   const float* x;

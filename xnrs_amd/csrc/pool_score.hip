@@ -56,8 +56,10 @@ __global__ __launch_bounds__(256) void additive_pool_kernel(AdditivePoolArgs a) 
   mpart = wave_sum(mpart);
   if (lane == 0) s_red[wave] = part;
   __syncthreads();
-  const float denom = (s_red[0] + s_red[1] + s_red[2] + s_red[3]) + 1e-8f;
+  const float sumw = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+  const float denom = sumw + 1e-8f;
   __syncthreads();
+  if (a.asum_out && tid == 0) a.asum_out[seq] = sumw / denom;
   if (a.hm_out) {
     if (lane == 0) s_red[wave] = mpart;
     __syncthreads();
@@ -77,6 +79,22 @@ __global__ __launch_bounds__(256) void additive_pool_kernel(AdditivePoolArgs a) 
     }
     a.y[seq * D + d] = acc;
   }
+}
+
+__global__ __launch_bounds__(256) void add_rowscaled_bias_kernel(float* p, int64_t ld, const float* s, const float* b, int64_t n, int D) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * D) return;
+  const int64_t r = i / D;
+  const int d = (int)(i - r * D);
+  p[r * ld + d] = fmaf(s[r], b[d], p[r * ld + d]);
+}
+
+hipError_t launch_add_rowscaled_bias(float* p, int64_t ld, const float* s, const float* b, int64_t n, int D, hipStream_t stream) {
+  if (n <= 0 || D <= 0) return hipSuccess;
+  const int64_t blocks = (n * D + 255) / 256;
+  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(add_rowscaled_bias_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, ld, s, b, n, D);
+  return hipGetLastError();
 }
 
 hipError_t launch_additive_pool(const AdditivePoolArgs& a, hipStream_t stream) {
