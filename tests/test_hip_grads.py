@@ -471,3 +471,50 @@ def test_attention_core_pair_kernel_branches(S, h, dk):
         H.assert_close(y_new, y_old, 2e-6, "tail kernel vs first-generation kernel")
     else:
         assert torch.equal(y_new, y_old)
+
+
+@pytest.mark.parametrize("live,bias", [(True, True), (False, True), (True, False)])
+def test_folded_out_projection_gradients(live, bias):
+    """Training with the out-projection folded behind the pooling (api.hip "fold": the forward pools the O rows, the
+    backward builds dO = a_i g + dpre W', dW1 = dW' Wo^T + db' (x) bo, dWo = dp^T po + W1^T dW', dbo = sum s dp + W1^T db')
+    against the per-token order (XNRS_FOLD_TRAIN=0) and oracle autograd: every parameter gradient and the input
+    gradient, with and without biases, over live rows and dense, masks with holes, an all-masked and a fully live news."""
+    from xnrs_amd import autograd as AG, hip
+    S, D, h, E, A = 24, 64, 4, 32, 48
+    enc, sd = load(news_encoding.TextEncoder(pooler=layers.AdditiveAttention(D, A), p_dropout=0.0, out_features=E,
+                                             in_features=D, att=layers.MultiHeadAttention(h, D), bias=bias), 191)
+    rng = synth.rng_for(192)
+    n = 150
+    x = torch.from_numpy(rng.standard_normal((n, S, D)).astype("float32"))
+    m = torch.from_numpy((rng.random((n, S)) < 0.6).astype("float32"))
+    m[:3] = 0
+    m[3] = 1
+    w = torch.from_numpy(rng.standard_normal((n, E)).astype("float32")).to(DEV)
+
+    def run(knob):
+        with hip.knobs(XNRS_FOLD_TRAIN=knob):
+            AG.LIVE_ROWS = live
+            try:
+                enc.zero_grad(set_to_none=True)
+                xd = x.to(DEV).requires_grad_(True)
+                y, _ = enc((xd.unsqueeze(0), m.to(DEV).reshape(1, n, S, 1)))
+                (y[0] * w).sum().backward()
+            finally:
+                AG.LIVE_ROWS = True
+        return y.detach(), xd.grad, {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None}
+
+    y0, dx0, g0 = run("0")
+    y1, dx1, g1 = run("1")
+    H.assert_close(y1, y0, 2e-5, "forward, folded vs per-token")
+    H.assert_close(dx1, dx0, 5e-5, "dx, folded vs per-token")
+    assert g0.keys() == g1.keys() and len(g0) >= (12 if bias else 7)
+    gmax = max(v.abs().max().item() for v in g0.values())
+    for k in g0:
+        scale = max(g0[k].abs().max().item(), 1e-3 * gmax)
+        assert (g1[k] - g0[k]).abs().max().item() / scale <= 5e-5, f"{k}: folded vs per-token gradient"
+    osd = oracle_sd(sd)
+    xo = x.clone().requires_grad_(True)
+    yo, _ = O.text_encoder(xo.unsqueeze(0), m.reshape(1, n, S, 1), osd, h)
+    (yo[0] * w.cpu()).sum().backward()
+    H.assert_close(dx1, xo.grad, GTOL, "dx vs oracle")
+    assert check_param_grads(enc, osd) >= (12 if bias else 7)

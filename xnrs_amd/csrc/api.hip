@@ -78,7 +78,7 @@ Plan make_plan(int64_t n_seq, int L, int D, int A, int E, bool att, bool additiv
   }
   p.off_nf = nfb ? take((nfb + 3) / 4) : 0;
   // folded out-projection (seq_encode "fold"): reserved whenever the shape is eligible, whatever the knob says
-  const bool foldable = att && additive && !train;
+  const bool foldable = att && additive;  // (training keeps W', b', the pooled O rows and the weight sums for the backward)
   p.off_fw = foldable ? take((size_t)A * D) : 0;
   p.off_fb = foldable ? take((size_t)A) : 0;
   p.off_po = foldable ? take((size_t)n_seq * D) : 0;
@@ -238,7 +238,7 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
   const bool fused = att && additive && !train && !a_out && att->dropout_p == 0.f && gemm_mode() == 0 &&
                      knobs().news_fused && news_fused_plan(L, D, att->n_heads, A, nullptr) &&
                      (D / att->n_heads) * att->n_heads == D && (knobs().news_fused == 2 || (L >= 26 && n_seq >= 192));
-  const bool fold = att && additive && !train && !fused && knobs().fold_out;
+  const bool fold = att && additive && !fused && (train ? knobs().fold_train : knobs().fold_out);
   float* wf = reinterpret_cast<float*>(w + p.off_fw);
   float* bf = reinterpret_cast<float*>(w + p.off_fb);
   float* pob = reinterpret_cast<float*>(w + p.off_po);
@@ -373,7 +373,7 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
 
       float* dst = pooled ? yb : y + c0 * (int64_t)L * D;
       if (fold) {
-        dst = o;  // the pooler works on the O rows (fold_out_projection)
+        dst = o;  // the pooler works on the O rows (fold_out_projection); masked rows of O are finite and carry weight 0
       } else if (live) {
         ProfScope ps(2, 2.0 * n_live * (double)D * D, stream);
         XNRS_TRY(hipMemsetAsync(dst, 0, (size_t)rows * D * sizeof(float), stream));
@@ -398,7 +398,7 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
         ProfScope ps(3, 2.0 * n_live * (double)D * A, stream);
         XNRS_TRY(hipMemsetAsync(t, 0, (size_t)rows * A * sizeof(float), stream));
         if (n_live > 0) {
-          GemmArgs fg = gemm1(seq, live_rows, 1, D, pool->w1, pool->b1, t, A, n_live, A, D, XNRS_ACT_TANH, p1);
+          GemmArgs fg = gemm1(seq, live_rows, 1, D, fc1_w, fc1_b, t, A, n_live, A, D, XNRS_ACT_TANH, p1);
           fg.c_scatter = 1;
           XNRS_TRY(launch_gemm_f32(fg, stream));
         }
@@ -777,6 +777,8 @@ namespace {
 
 struct BwdPlan {
   size_t off_dh, off_dp, off_dseq, off_dpre, off_de, off_docat, off_dqkv, off_delta, off_slabs, off_colsum, off_wt;
+  // folded out-projection (training): g = dp.Wo, c = dp.bo, dW', db', the stacked operands of dWo / dbo
+  size_t off_g, off_c, off_dwf, off_dbf, off_sta, off_stb, off_stw;
   size_t total;
 };
 
@@ -800,10 +802,19 @@ BwdPlan make_bwd_plan(int64_t n_seq, int L, int D, int A, int E, int n_heads, bo
   p.off_docat = att ? take(rows * D * 4) : 0;
   p.off_dqkv = att ? take(rows * 3 * D * 4) : 0;
   p.off_delta = att ? take((size_t)n_seq * n_heads * L * 4) : 0;
+  const bool foldable = att && additive;
+  p.off_g = foldable ? take((size_t)n_seq * D * 4) : 0;
+  p.off_c = foldable ? take((size_t)n_seq * 4) : 0;
+  p.off_dwf = foldable ? take((size_t)A * D * 4) : 0;
+  p.off_dbf = foldable ? take((size_t)A * 4) : 0;
+  p.off_sta = foldable ? take(((size_t)n_seq + A) * D * 4) : 0;
+  p.off_stb = foldable ? take(((size_t)n_seq + A) * D * 4) : 0;
+  p.off_stw = foldable ? take(((size_t)n_seq + A) * 4) : 0;
   // split-K slabs: the largest dW this pipeline produces
   size_t slabs = 0;
   if (att) slabs = max_sz(slabs, gemm_splitk_workspace_bytes(D, D, rows));
   if (additive) slabs = max_sz(slabs, gemm_splitk_workspace_bytes(A, D, rows));
+  if (foldable) slabs = max_sz(slabs, gemm_splitk_workspace_bytes(D, D, (int64_t)n_seq + A));  // stacked dWo product
   if (pooled && head) {
     slabs = max_sz(slabs, gemm_splitk_workspace_bytes(E, D, n_seq));
     slabs = max_sz(slabs, gemm_splitk_workspace_bytes(E, E, n_seq));
@@ -1013,6 +1024,7 @@ int32_t xnrs_seq_encoder_bwd_live(const float* x, const float* m, const int32_t*
   const int32_t* lv = live ? live_rows : nullptr;
   const int32_t* lvx = live ? (live_src_rows ? live_src_rows : live_rows) : nullptr;
   if (live_rows && ids && !live_src_rows) return XNRS_EINVAL;  // a gathered table needs the table rows of the live tokens
+  const bool fold = att && pooled && additive && knobs().fold_train;  // must match the forward that wrote `saved`
 
   // gradient w.r.t. the sequence rows that fed the pooler (att output, or x itself)
   const float* dseq_src = nullptr;  // [rows, D]
@@ -1033,6 +1045,69 @@ int32_t xnrs_seq_encoder_bwd_live(const float* x, const float* m, const int32_t*
       dpool = dp;
     }
     // ---- pooler
+    if (fold) {
+      // Folded out-projection (seq_encode "fold"; the forward saved O, tanh(W' O + b'), a, the pooled O rows and sum a):
+      //   p = Wo po + bo s,  po = sum_i a_i O_i,  s = sum_i a_i;   pre_i = W' O_i + b',  W' = W1 Wo,  b' = W1 bo + b1
+      //   g = Wo^T dp, c = dp . bo:  da_i = g . O_i + c,  dO_i = a_i g + dpre_i W'
+      //   dW' = dpre^T O, db' = sum dpre:  dW1 = dW' Wo^T + db' (x) bo,  db1 = db'
+      //   dWo = dp^T po + W1^T dW',  dbo = sum_n s_n dp_n + W1^T db'      (one stacked product / column sum each)
+      // The three rows x D x D products of the per-token order (forward out-projection, dO = dY Wo, dWo = dY^T O) are gone.
+      const float* wf = reinterpret_cast<const float*>(sv + sp.off_fw);
+      const float* pob = reinterpret_cast<const float*>(sv + sp.off_po);
+      const float* asum = reinterpret_cast<const float*>(sv + sp.off_as);
+      float* gvec = reinterpret_cast<float*>(w + bp.off_g);
+      float* cvec = reinterpret_cast<float*>(w + bp.off_c);
+      float* dwf = reinterpret_cast<float*>(w + bp.off_dwf);
+      float* dbf = reinterpret_cast<float*>(w + bp.off_dbf);
+      float* sta = reinterpret_cast<float*>(w + bp.off_sta);
+      float* stb = reinterpret_cast<float*>(w + bp.off_stb);
+      float* stw = reinterpret_cast<float*>(w + bp.off_stw);
+      XNRS_TRY(gemm_dx(dpool, D, att->wo, gvec, D, n_seq, D, D, nullptr, 0, 0, 0, stream, wt));
+      if (att->bo)
+        XNRS_TRY(launch_gemm_f32(gemm1(dpool, nullptr, 0, D, att->bo, nullptr, cvec, 1, n_seq, 1, D, XNRS_ACT_NONE), stream));
+      AdditivePoolBwdArgs pa{};
+      pa.dp = gvec;
+      pa.x = o;
+      pa.ldx = D;
+      pa.a = a_sv;
+      pa.t = t;
+      pa.w2 = pool->w2;
+      pa.dx = docat;  // dO_i = a_i g (every row written; masked rows get 0)
+      pa.lddx = D;
+      pa.dpre = dpre;
+      pa.de = de;
+      pa.da_shift = att->bo ? cvec : nullptr;
+      pa.n_seq = n_seq;
+      pa.N = L;
+      pa.D = D;
+      pa.A = A;
+      XNRS_TRY(launch_additive_pool_bwd(pa, stream));
+      if (g_pool && g_pool->w2) XNRS_TRY(launch_colsum(t, A, de, rows, A, g_pool->w2, csum, stream));
+      if (g_pool && g_pool->b2) XNRS_TRY(launch_colsum(de, 1, nullptr, rows, 1, g_pool->b2, csum, stream));
+      XNRS_TRY(gemm_dw(dpre, A, o, nullptr, 0, D, dwf, rows, A, D, slabs, stream, lv, lv, n_live, dbf, csum));
+      XNRS_TRY(gemm_dx(dpre, A, wf, docat, D, rows, A, D, nullptr, 0, 0, /*accumulate*/ 1, stream, wt, lv, n_live));
+      if (g_pool && g_pool->w1) {
+        XNRS_TRY(launch_gemm_f32(gemm1(dwf, nullptr, 0, D, att->wo, nullptr, g_pool->w1, D, A, D, D, XNRS_ACT_NONE), stream));
+        if (att->bo) XNRS_TRY(launch_add_rowscaled_bias(g_pool->w1, D, dbf, att->bo, A, D, stream));
+      }
+      if (g_pool && g_pool->b1)
+        XNRS_TRY(hipMemcpyAsync(g_pool->b1, dbf, (size_t)A * sizeof(float), hipMemcpyDeviceToDevice, stream));
+      if (g_att && (g_att->wo || g_att->bo)) {
+        const size_t nd = (size_t)n_seq * D * sizeof(float), ad = (size_t)A * D * sizeof(float);
+        XNRS_TRY(hipMemcpyAsync(sta, dpool, nd, hipMemcpyDeviceToDevice, stream));
+        XNRS_TRY(hipMemcpyAsync(sta + (size_t)n_seq * D, pool->w1, ad, hipMemcpyDeviceToDevice, stream));
+        if (g_att->wo) {
+          XNRS_TRY(hipMemcpyAsync(stb, pob, nd, hipMemcpyDeviceToDevice, stream));
+          XNRS_TRY(hipMemcpyAsync(stb + (size_t)n_seq * D, dwf, ad, hipMemcpyDeviceToDevice, stream));
+          XNRS_TRY(gemm_dw(sta, D, stb, nullptr, 0, D, g_att->wo, n_seq + A, D, D, slabs, stream));
+        }
+        if (g_att->bo) {
+          XNRS_TRY(hipMemcpyAsync(stw, asum, (size_t)n_seq * sizeof(float), hipMemcpyDeviceToDevice, stream));
+          XNRS_TRY(hipMemcpyAsync(stw + n_seq, dbf, (size_t)A * sizeof(float), hipMemcpyDeviceToDevice, stream));
+          XNRS_TRY(launch_colsum(sta, D, stw, n_seq + A, D, g_att->bo, csum, stream));
+        }
+      }
+    } else {
     const float* seq = att ? yatt : x;
     const int32_t* seq_ids = att ? nullptr : ids;
     const bool need_dseq = att || dx;
@@ -1066,17 +1141,20 @@ int32_t xnrs_seq_encoder_bwd_live(const float* x, const float* m, const int32_t*
       XNRS_TRY(launch_mean_pool_bwd(dpool, m, ids, dseq_dst, D, n_seq, L, D, stream));
     }
     dseq_src = dseq_dst;
+    }
   } else {
     dseq_src = dy;  // MultiHeadAttention alone: dy is the gradient of the attention output
   }
   if (!att) return XNRS_OK;
 
-  // ---- out projection: yatt = O Wo^T + bo
-  if (g_att && g_att->wo)
-    XNRS_TRY(gemm_dw(dseq_src, D, o, nullptr, 0, D, g_att->wo, rows, D, D, slabs, stream, lv, lv, n_live, g_att->bo, csum));
-  else if (g_att && g_att->bo) XNRS_TRY(launch_colsum(dseq_src, D, nullptr, rows, D, g_att->bo, csum, stream));
-  if (live) XNRS_TRY(hipMemsetAsync(docat, 0, (size_t)rows * D * sizeof(float), stream));  // dO of a masked row is zero
-  XNRS_TRY(gemm_dx(dseq_src, D, att->wo, docat, D, rows, D, D, nullptr, 0, 0, 0, stream, wt, lv, n_live));
+  // ---- out projection: yatt = O Wo^T + bo   (folded: docat and the Wo / bo gradients are complete already)
+  if (!fold) {
+    if (g_att && g_att->wo)
+      XNRS_TRY(gemm_dw(dseq_src, D, o, nullptr, 0, D, g_att->wo, rows, D, D, slabs, stream, lv, lv, n_live, g_att->bo, csum));
+    else if (g_att && g_att->bo) XNRS_TRY(launch_colsum(dseq_src, D, nullptr, rows, D, g_att->bo, csum, stream));
+    if (live) XNRS_TRY(hipMemsetAsync(docat, 0, (size_t)rows * D * sizeof(float), stream));  // dO of a masked row is zero
+    XNRS_TRY(gemm_dx(dseq_src, D, att->wo, docat, D, rows, D, D, nullptr, 0, 0, 0, stream, wt, lv, n_live));
+  }
   // ---- attention core
   MhaBwdArgs mb{};
   mb.q = qkv;

@@ -21,6 +21,7 @@ struct Knobs {
   long long gemm_group = -1;    // XNRS_GEMM_GROUP=n column tiles per walk group (0 = plain walk); -1 = automatic
   int gemm_tile = -1;           // XNRS_GEMM_TILE=0..3 force a block tile; -1 = cost model
   long long split_min_tiles = 512;  // XNRS_GEMM_SPLIT_MIN_TILES: smallest launch the bf16-split kernel takes
+  bool fold_train = true;       // XNRS_FOLD_TRAIN=0: the training forward / backward keep the per-token out-projection
   bool fold_out = true;         // XNRS_FOLD_OUT=0: inference keeps the per-token out-projection (api.hip "fold")
   int gemm_dw = 1;              // XNRS_GEMM_DW: 1 = live-row weight gradients on gemm_dw.hip, 2 = every eligible one, 0 = none
   int mha_lds = -1;             // XNRS_MHA_LDS=0|1 force / forbid the LDS-staged attention kernel; -1 = by shape
@@ -259,6 +260,7 @@ struct AdditivePoolBwdArgs {
   int64_t lddx;
   float* dpre;       // [n_seq*N, A] gradient at the fc1 pre-activation
   float* de;         // [n_seq*N] gradient at the fc2 output (score)
+  const float* da_shift;  // nullable [n_seq]: added to every da_i of the sequence (folded out-projection: dp . bo)
   int64_t n_seq;
   int32_t N, D, A;
 };

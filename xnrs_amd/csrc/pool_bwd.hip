@@ -30,13 +30,14 @@ __global__ __launch_bounds__(256) void additive_pool_bwd_kernel(AdditivePoolBwdA
   const int64_t srcx = a.x_gather_ids ? (int64_t)a.x_gather_ids[seq] : seq;
   const float* x = a.x + srcx * N * a.ldx;
   const float* dp = a.dp + seq * D;
+  const float shift = a.da_shift ? a.da_shift[seq] : 0.f;
   for (int i = wave; i < N; i += 4) {
     const float* xi = x + (int64_t)i * a.ldx;
     float acc = 0.f;
     for (int d = lane; d < D; d += 64) acc = fmaf(dp[d], xi[d], acc);
     acc = wave_sum_b(acc);
     if (lane == 0) {
-      s_da[i] = acc;
+      s_da[i] = acc + shift;
       s_a[i] = a.a[seq * N + i];
     }
   }
