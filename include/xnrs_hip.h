@@ -110,7 +110,9 @@ int32_t xnrs_collapse_mask(const float *m, float *hm, int64_t n_rows, int32_t S,
  * x:(n_news,S,D) [or table + ids, see xnrs_linear_fwd], m:(n_news,S) -> y:(n_news,E'), hm:(n_news).
  * att == NULL: no self-attention stage; head == NULL: y is the pooled D-vector (E' = D).
  * If ids != NULL, x and m are the TABLE ([n_table,S,D], [n_table,S]) and n_news = len(ids).
- * `chunk` = news per internal pass (bounds the workspace; 0 = library default). */
+ * `chunk` = news per internal pass (bounds the workspace; 0 = library default).
+ * With an attention stage and the additive pooler the out-projection (layers.py:154) is applied once per news behind
+ * the pooling (exact algebra); <= 32 tokens and D <= 320 run as one fused kernel (section 4.4). */
 size_t xnrs_text_encoder_workspace_bytes(int64_t n_news, int32_t S, int32_t D, int32_t A, int32_t E,
                                          int32_t has_att, int32_t pool_kind, int32_t has_head,
                                          int64_t chunk);
@@ -319,9 +321,12 @@ int32_t xnrs_get_gemm_mode(void);
 
 /* ---- development knobs (no reference counterpart) ---------------------------------------------
  * Kernel-selection switches for A/B measurements and tests (XNRS_GEMM_PIPE, _BK, _BUF, _GROUP, _TILE,
- * XNRS_GEMM_SPLIT_MIN_TILES, XNRS_MHA_LDS, XNRS_MHA_HEADWAVE, XNRS_MHA_BWD_FUSED, XNRS_NEWS_FUSED; DESIGN.md
- * section 6).  The library reads them from the environment ONCE when it is loaded -- no launch calls getenv --
- * and again only when this function is called.  None changes a result beyond summation order. */
+ * XNRS_GEMM_SPLIT_MIN_TILES, XNRS_GEMM_DW, XNRS_MHA_LDS, XNRS_MHA_HEADWAVE, XNRS_MHA_PAIR, XNRS_MHA_BWD_FUSED,
+ * XNRS_NEWS_FUSED, XNRS_NEWS_FUSED_NPW, XNRS_FOLD_OUT, XNRS_FOLD_TRAIN).  The library reads
+ * them from the environment ONCE when it is loaded -- no launch calls getenv -- and again only when this function is
+ * called.  None changes a result beyond summation / association order (XNRS_FOLD_*: whether the attention
+ * out-projection is applied per token row, as the reference writes it, or once per sequence behind the additive
+ * pooling; XNRS_FOLD_TRAIN must not change between a training forward and its backward). */
 int32_t xnrs_reload_knobs(void);
 
 #ifdef __cplusplus
