@@ -67,6 +67,7 @@ def news_flops(S, D, A, E, att=True, head=True, folded=False):
 
 
 def fold_on():
+    """Does the library fold the out-projection behind the pooling?  (XNRS_FOLD_OUT=0: no.)"""
     return os.environ.get("XNRS_FOLD_OUT", "1") != "0"
 
 

@@ -423,7 +423,8 @@ def test_folded_out_projection_matches_per_token_out_projection(S, D, h, A, bias
                 y, hm = enc((x.to(DEV).unsqueeze(0), m.to(DEV).reshape(1, n, S, 1)))
         return y[0], hm[0]
 
-    y1, hm1 = run()
+    with hip.knobs(XNRS_FOLD_OUT="2"):
+        y1, hm1 = run()
     with hip.knobs(XNRS_FOLD_OUT="0"):
         y0, hm0 = run()
     assert torch.equal(hm0, hm1)
@@ -439,7 +440,8 @@ def test_folded_out_projection_matches_per_token_out_projection(S, D, h, A, bias
     hx = torch.from_numpy(rng.standard_normal((5, S, D)).astype("float32"))
     hmask = torch.from_numpy((rng.random((5, S, 1)) < 0.7).astype("float32"))
     with torch.no_grad():
-        u1, a1 = ue((hx.to(DEV), hmask.to(DEV)), return_weights=True)
+        with hip.knobs(XNRS_FOLD_OUT="2"):
+            u1, a1 = ue((hx.to(DEV), hmask.to(DEV)), return_weights=True)
         with hip.knobs(XNRS_FOLD_OUT="0"):
             u0, a0 = ue((hx.to(DEV), hmask.to(DEV)), return_weights=True)
     H.assert_close(u1, u0, 2e-5, "user vector, folded vs per-token")

@@ -27,13 +27,15 @@ namespace {
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
+constexpr int FOLD_SPLITS = 8;  // K slices of the folded-weight product W1 . Wo (slabs: FOLD_SPLITS x A x D floats in the plan)
+
 struct Plan {
   int64_t chunk;  // sequences per pass
   size_t off_qkv, off_o, off_y, off_t, off_p, off_h;
   size_t off_stats, off_a;  // training only: softmax row statistics, pooling weights
   size_t off_planes;        // bf16-split GEMM modes: pre-split weight planes (wq, wk, wv, wo, w1)
   size_t off_nf;            // fused short-sequence encoder: fragment-ordered weight images
-  size_t off_fw, off_fb, off_po, off_as;  // folded out-projection (inference): W1.Wo, W1.bo + b1, pooled O rows, sum of weights
+  size_t off_fw, off_fb, off_po, off_as, off_fsl;  // folded out-projection: W1.Wo, W1.bo + b1, pooled O rows, sum of weights, split-K slabs
   size_t total;
 };
 
@@ -83,6 +85,7 @@ Plan make_plan(int64_t n_seq, int L, int D, int A, int E, bool att, bool additiv
   p.off_fb = foldable ? take((size_t)A) : 0;
   p.off_po = foldable ? take((size_t)n_seq * D) : 0;
   p.off_as = foldable ? take((size_t)n_seq) : 0;
+  p.off_fsl = foldable ? take((size_t)FOLD_SPLITS * A * D) : 0;
   p.total = off;
   return p;
 }
@@ -162,9 +165,18 @@ GemmArgs gemm1(const float* A, const int32_t* ids, int gS, int64_t lda, const fl
 // A x D x D product for the folded weight per call (0.3 GFLOP; the ABI keeps no state between calls).  Exact algebra for
 // every input -- only the rounding order differs from the reference's (observed <= 2e-6 on the scores, bar 1e-4); the
 // training forward keeps Y (the backward needs it).  XNRS_FOLD_OUT=0 keeps the per-token out-projection.
+// The folded weight is rebuilt per call (the ABI keeps no state): a split-K product over 8 slices and a wave-per-row bias
+// kernel, ~20 us per call at D = 768 -- three short launches.  One impression (1 250 + 250 token rows, three encoder calls)
+// pays for that: 0.33 -> 0.39 ms (a single unsliced product made it 0.44); from a few thousand token rows on the fold wins,
+// +25 % at the benchmark batch.  The choice deliberately never depends on the batch size -- a news item's vector must not change in the last bit with the batch
+// it is encoded in (chunking, id gather, skip_empty and the padding-free path are all tested bitwise against the plain
+// path).  Knob: 0 never, anything else always.
 // Returns the fc1 bias to use (nullptr if there is none).
+bool fold_wanted(int knob) { return knob != 0; }
+
+
 const float* fold_out_projection(const xnrs_mha_params* att, const xnrs_additive_params* pool, int D, int A, float* wf,
-                                 float* bf, hipStream_t stream, hipError_t* err) {
+                                 float* bf, float* slabs, hipStream_t stream, hipError_t* err) {
   GemmArgs g{};  // wf[A][D] = W1[A][D] . Wo[D][D]   (B k-major: its row index is the contraction index)
   g.A = pool->w1;
   g.lda = D;
@@ -177,10 +189,13 @@ const float* fold_out_projection(const xnrs_mha_params* att, const xnrs_additive
   g.ldc = D;
   g.M = A;
   g.K = D;
+  if (D >= 64 * FOLD_SPLITS) {  // enough contraction to slice: 8 x the workgroups, fixed-order reduce (bitwise reproducible)
+    g.slabs = slabs;
+    g.nsplit = FOLD_SPLITS;
+  }
   *err = launch_gemm_f32(g, stream);
   if (*err != hipSuccess || !att->bo) return pool->b1;
-  // bf[1][A] = bo[1][D] . W1[A][D]^T + b1
-  *err = launch_gemm_f32(gemm1(att->bo, nullptr, 0, D, pool->w1, pool->b1, bf, A, 1, A, D, XNRS_ACT_NONE), stream);
+  *err = launch_fold_bias(pool->w1, att->bo, pool->b1, bf, A, D, stream);  // bf = W1 . bo + b1
   return bf;
 }
 
@@ -238,7 +253,7 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
   const bool fused = att && additive && !train && !a_out && att->dropout_p == 0.f && gemm_mode() == 0 &&
                      knobs().news_fused && news_fused_plan(L, D, att->n_heads, A, nullptr) &&
                      (D / att->n_heads) * att->n_heads == D && (knobs().news_fused == 2 || (L >= 26 && n_seq >= 192));
-  const bool fold = att && additive && !fused && (train ? knobs().fold_train : knobs().fold_out);
+  const bool fold = att && additive && !fused && fold_wanted(train ? knobs().fold_train : knobs().fold_out);
   float* wf = reinterpret_cast<float*>(w + p.off_fw);
   float* bf = reinterpret_cast<float*>(w + p.off_fb);
   float* pob = reinterpret_cast<float*>(w + p.off_po);
@@ -247,7 +262,7 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
   const float* fc1_b = additive ? pool->b1 : nullptr;
   if (fold) {
     hipError_t fe = hipSuccess;
-    fc1_b = fold_out_projection(att, pool, D, A, wf, bf, stream, &fe);
+    fc1_b = fold_out_projection(att, pool, D, A, wf, bf, reinterpret_cast<float*>(w + p.off_fsl), stream, &fe);
     XNRS_TRY(fe);
     fc1_w = wf;
   }
@@ -536,7 +551,7 @@ int32_t xnrs_text_encoder_fwd(const float* x, const float* m, const int32_t* ids
 // ---- unpadded news encoder (inference): workspace carve, every region 256-B aligned
 namespace {
 struct UnpadPlan {
-  size_t off_kv, off_q, off_o, off_y, off_t, off_p, off_h, off_fw, off_fb, off_po, off_as, total;
+  size_t off_kv, off_q, off_o, off_y, off_t, off_p, off_h, off_fw, off_fb, off_po, off_as, off_fsl, total;
 };
 UnpadPlan make_unpad_plan(int64_t n_news, int64_t n_valid, int S, int D, int A, int E, bool att, bool head) {
   UnpadPlan p{};
@@ -558,6 +573,7 @@ UnpadPlan make_unpad_plan(int64_t n_news, int64_t n_valid, int S, int D, int A, 
   p.off_fb = att ? take((size_t)A) : 0;
   p.off_po = att ? take((size_t)n_news * D) : 0;
   p.off_as = att ? take((size_t)n_news) : 0;
+  p.off_fsl = att ? take((size_t)FOLD_SPLITS * A * D) : 0;
   p.total = cur;
   return p;
 }
@@ -598,7 +614,7 @@ int32_t xnrs_text_encoder_fwd_unpadded(const float* x, const int32_t* ids, int64
   const float* vals = x;          // what the pooler weights: compact y rows, or x rows through `rows`
   const int32_t* val_ids = rows;
   // the same folded out-projection as the padded path (seq_encode "fold"), so the two stay bitwise equal
-  const bool fold = att && knobs().fold_out;
+  const bool fold = att && fold_wanted(knobs().fold_out);
   float* wf = reinterpret_cast<float*>(w + p.off_fw);
   float* bf = reinterpret_cast<float*>(w + p.off_fb);
   float* pob = reinterpret_cast<float*>(w + p.off_po);
@@ -607,7 +623,7 @@ int32_t xnrs_text_encoder_fwd_unpadded(const float* x, const int32_t* ids, int64
   const float* fc1_b = pool->b1;
   if (fold) {
     hipError_t fe = hipSuccess;
-    fc1_b = fold_out_projection(att, pool, D, A, wf, bf, stream, &fe);
+    fc1_b = fold_out_projection(att, pool, D, A, wf, bf, reinterpret_cast<float*>(w + p.off_fsl), stream, &fe);
     XNRS_TRY(fe);
     fc1_w = wf;
   }
@@ -1024,7 +1040,7 @@ int32_t xnrs_seq_encoder_bwd_live(const float* x, const float* m, const int32_t*
   const int32_t* lv = live ? live_rows : nullptr;
   const int32_t* lvx = live ? (live_src_rows ? live_src_rows : live_rows) : nullptr;
   if (live_rows && ids && !live_src_rows) return XNRS_EINVAL;  // a gathered table needs the table rows of the live tokens
-  const bool fold = att && pooled && additive && knobs().fold_train;  // must match the forward that wrote `saved`
+  const bool fold = att && pooled && additive && fold_wanted(knobs().fold_train);  // = the forward's decision
 
   // gradient w.r.t. the sequence rows that fed the pooler (att output, or x itself)
   const float* dseq_src = nullptr;  // [rows, D]

@@ -759,8 +759,8 @@ static Knobs read_knobs() {
   k.mha_pair = num("XNRS_MHA_PAIR", 1) != 0;
   k.mha_bwd_fused = num("XNRS_MHA_BWD_FUSED", 1) != 0;
   k.gemm_dw = (int)num("XNRS_GEMM_DW", 1);
-  k.fold_out = num("XNRS_FOLD_OUT", 1) != 0;
-  k.fold_train = num("XNRS_FOLD_TRAIN", 1) != 0;
+  k.fold_out = (int)num("XNRS_FOLD_OUT", 1);
+  k.fold_train = (int)num("XNRS_FOLD_TRAIN", 1);
   k.news_fused = (int)num("XNRS_NEWS_FUSED", 1);
   k.news_fused_npw = (int)num("XNRS_NEWS_FUSED_NPW", 0);
   const long long m = num("XNRS_GEMM_MODE", 0);

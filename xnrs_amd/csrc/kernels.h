@@ -21,8 +21,8 @@ struct Knobs {
   long long gemm_group = -1;    // XNRS_GEMM_GROUP=n column tiles per walk group (0 = plain walk); -1 = automatic
   int gemm_tile = -1;           // XNRS_GEMM_TILE=0..3 force a block tile; -1 = cost model
   long long split_min_tiles = 512;  // XNRS_GEMM_SPLIT_MIN_TILES: smallest launch the bf16-split kernel takes
-  bool fold_train = true;       // XNRS_FOLD_TRAIN=0: the training forward / backward keep the per-token out-projection
-  bool fold_out = true;         // XNRS_FOLD_OUT=0: inference keeps the per-token out-projection (api.hip "fold")
+  int fold_train = 1;           // XNRS_FOLD_TRAIN=0: the training forward / backward keep the per-token out-projection
+  int fold_out = 1;             // XNRS_FOLD_OUT=0: inference keeps the per-token out-projection (api.hip "fold")
   int gemm_dw = 1;              // XNRS_GEMM_DW: 1 = live-row weight gradients on gemm_dw.hip, 2 = every eligible one, 0 = none
   int mha_lds = -1;             // XNRS_MHA_LDS=0|1 force / forbid the LDS-staged attention kernel; -1 = by shape
   bool mha_pair = true;         // XNRS_MHA_PAIR=0: the first-generation LDS-staged attention kernel instead of mha_core_pair_kernel
@@ -232,6 +232,8 @@ struct AdditivePoolArgs {
 };
 hipError_t launch_additive_pool(const AdditivePoolArgs& a, hipStream_t stream);
 // p[n][d] += s[n] * b[d]   (the out-projection bias behind a pooled out-projection, api.hip "fold")
+// bf[a] = W1[a,:] . bo + b1[a]  (b1 nullable): the fc1 bias behind a folded out-projection
+hipError_t launch_fold_bias(const float* w1, const float* bo, const float* b1, float* bf, int A, int D, hipStream_t stream);
 hipError_t launch_add_rowscaled_bias(float* p, int64_t ld, const float* s, const float* b, int64_t n, int D, hipStream_t stream);
 
 struct MeanPoolArgs {

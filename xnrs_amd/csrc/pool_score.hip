@@ -89,6 +89,21 @@ __global__ __launch_bounds__(256) void add_rowscaled_bias_kernel(float* p, int64
   p[r * ld + d] = fmaf(s[r], b[d], p[r * ld + d]);
 }
 
+__global__ __launch_bounds__(256) void fold_bias_kernel(const float* w1, const float* bo, const float* b1, float* bf, int A, int D) {
+  const int a = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (a >= A) return;  // wave-uniform
+  float acc = 0.f;
+  for (int d = lane; d < D; d += 64) acc = fmaf(w1[(int64_t)a * D + d], bo[d], acc);
+  acc = wave_sum(acc);
+  if (lane == 0) bf[a] = acc + (b1 ? b1[a] : 0.f);
+}
+
+hipError_t launch_fold_bias(const float* w1, const float* bo, const float* b1, float* bf, int A, int D, hipStream_t stream) {
+  if (A <= 0) return hipSuccess;
+  hipLaunchKernelGGL(fold_bias_kernel, dim3((unsigned)((A + 3) / 4)), dim3(256), 0, stream, w1, bo, b1, bf, A, D);
+  return hipGetLastError();
+}
+
 hipError_t launch_add_rowscaled_bias(float* p, int64_t ld, const float* s, const float* b, int64_t n, int D, hipStream_t stream) {
   if (n <= 0 || D <= 0) return hipSuccess;
   const int64_t blocks = (n * D + 255) / 256;
