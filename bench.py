@@ -754,7 +754,11 @@ def main():
                                    "(BASELINE configs[2]; token shape of config/mind_small_NRMS.yml)",
                        "batch_impressions_per_gpu": w["B"], "history": w["H"], "candidates": w["C"],
                        "tokens": w["S"], "d_backbone": w["D"], "n_heads": w["h"], "emb_dim": w["E"],
-                       "parallelism": f"impressions sharded by user over {n_gpus} GPU(s), no data-path collective"},
+                       "parallelism": f"impressions sharded by user over {n_gpus} GPU(s), no data-path collective",
+                       "operation_order": ("every layer of the reference applied to every input; the attention out-projection is "
+                                           "applied once per news behind the additive pooling instead of once per token (exact "
+                                           "algebra, recomputed inside every timed step; extra.per_token_out_projection = the "
+                                           "reference's order)" if fold_on() else "the reference's (XNRS_FOLD_OUT=0)")},
             # modes 1/2 issue `mode_products` bf16 MFMA products per algorithmic fp32 product: achieved = issued
             # matrix flops against the dense bf16 peak
             "roofline": {"bound": "mfma", "achieved": ach * mode_products,
