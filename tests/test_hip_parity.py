@@ -449,3 +449,49 @@ def test_folded_out_projection_matches_per_token_out_projection(S, D, h, A, bias
     uo, ao = O.user_encoder(hx, hmask, usd, h, return_weights=True)
     H.assert_close(u1, uo, what="user vector vs oracle")
     H.assert_close(a1, ao, what="pooling weights vs oracle")
+
+
+@pytest.mark.parametrize("S,D,h,A", [(50, 64, 4, 48), (40, 96, 3, 100), (33, 128, 8, 256), (9, 32, 2, 16), (64, 64, 2, 33)])
+def test_fc2_dot_in_the_fc1_epilogue(S, D, h, A):
+    """Inference takes the additive pooler's score w2 . tanh(fc1 x) per block of 32 hidden columns in the fc1 GEMM's
+    epilogue (GemmArgs::rowdot_out: tanh(fc1 x) is never stored; the pooling kernel adds the blocks in column order).
+    Against the materialised-T path (XNRS_FC1_ROWDOT=0) and the oracle: hidden sizes that are / are not multiples of 32,
+    ragged row tiles, pooling weights of the user tower, and the padding-free path bitwise equal to the padded one."""
+    from xnrs_amd import hip
+    enc, sd = load(news_encoding.TextEncoder(pooler=layers.AdditiveAttention(D, A), p_dropout=0.0, out_features=24,
+                                             in_features=D, att=layers.MultiHeadAttention(h, D)), 511)
+    rng = synth.rng_for(512 + A)
+    n = 41
+    x = torch.from_numpy(rng.standard_normal((n, S, D)).astype("float32"))
+    lens = rng.integers(0, S + 1, size=(n,))
+    m = torch.from_numpy((np.arange(S)[None, :] < lens[:, None]).astype("float32"))  # prefix masks (the data's shape)
+
+    def run(unpadded=False):
+        enc.unpadded = unpadded
+        try:
+            with torch.no_grad():
+                y, hm = enc((x.to(DEV).unsqueeze(0), m.to(DEV).reshape(1, n, S, 1)))
+        finally:
+            enc.unpadded = False
+        return y[0], hm[0]
+
+    y1, hm1 = run()
+    with hip.knobs(XNRS_FC1_ROWDOT="0"):
+        y0, hm0 = run()
+    assert torch.equal(hm0, hm1)
+    H.assert_close(y1, y0, 2e-5, "epilogue dot vs materialised tanh(fc1 x)")
+    yo, _ = O.text_encoder(x.unsqueeze(0), m.reshape(1, n, S, 1), sd, h)
+    H.assert_close(y1, yo[0], what="epilogue dot vs oracle")
+    if S <= 64 and (D // h) % 4 == 0:
+        y2, hm2 = run(unpadded=True)
+        assert torch.equal(y2, y1) and torch.equal(hm2, hm1)
+
+    ue, usd = load(user_encoding.UserEncoder(pooler=layers.AdditiveAttention(D, A), p_dropout=0.0, emb_dim=D,
+                                             att=layers.MultiHeadAttention(h, D)), 513)
+    hx = torch.from_numpy(rng.standard_normal((6, S, D)).astype("float32"))
+    hmask = torch.from_numpy((rng.random((6, S, 1)) < 0.7).astype("float32"))
+    with torch.no_grad():
+        u1, a1 = ue((hx.to(DEV), hmask.to(DEV)), return_weights=True)
+    uo, ao = O.user_encoder(hx, hmask, usd, h, return_weights=True)
+    H.assert_close(u1, uo, what="user vector vs oracle")
+    H.assert_close(a1, ao, what="pooling weights vs oracle")

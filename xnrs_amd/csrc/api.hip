@@ -174,6 +174,13 @@ GemmArgs gemm1(const float* A, const int32_t* ids, int gS, int64_t lda, const fl
 // Returns the fc1 bias to use (nullptr if there is none).
 bool fold_wanted(int knob) { return knob != 0; }
 
+// the fused row dots ride on the raw-buffer-load forward kernel: 16-byte aligned operands
+bool fc1_rowdot_ok(const float* x, bool att, const xnrs_additive_params* pool, int64_t rows, int D) {
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return knobs().fc1_rowdot && knobs().gemm_buf && gemm_mode() == 0 && pool && pool->w2 && D % 4 == 0 && al16(pool->w1) &&
+         (att || al16(x)) && rows * D * 4 <= (1ll << 30) && (int64_t)pool->hidden * D * 4 <= (1ll << 30);
+}
+
 
 const float* fold_out_projection(const xnrs_mha_params* att, const xnrs_additive_params* pool, int D, int A, float* wf,
                                  float* bf, float* slabs, hipStream_t stream, hipError_t* err) {
@@ -258,6 +265,12 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
   float* bf = reinterpret_cast<float*>(w + p.off_fb);
   float* pob = reinterpret_cast<float*>(w + p.off_po);
   float* asum = reinterpret_cast<float*>(w + p.off_as);
+  // inference, fp32 GEMM mode, 16-byte-aligned shapes the buffer-load kernel serves, no gathered rows: the pooler's fc2
+  // dot is taken in the fc1 epilogue (GemmArgs::rowdot_out; the T region then holds A/32 partial dots per row)
+  const int n_ep = (A + 31) / 32;
+  // (attention towers only: there the fc1 input is the dense O / Y image whatever the input path -- ids, padded,
+  // unpadded --, so all of them take the same route and stay bitwise equal)
+  const bool rowdot = att && additive && !train && !fused && fc1_rowdot_ok(x, true, pool, p.chunk * (int64_t)L, D);
   const float* fc1_w = additive ? pool->w1 : nullptr;
   const float* fc1_b = additive ? pool->b1 : nullptr;
   if (fold) {
@@ -419,10 +432,18 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
         }
       } else {
         ProfScope ps(3, 2.0 * rows * (double)D * A, stream);
-        XNRS_TRY(launch_gemm_f32(gemm1(seq, seq_ids, L, D, fc1_w, fc1_b, t, A, rows, A, D, XNRS_ACT_TANH, p1), stream));
+        GemmArgs fg = gemm1(seq, seq_ids, L, D, fc1_w, fc1_b, t, A, rows, A, D, XNRS_ACT_TANH, p1);
+        if (rowdot) {  // the fc2 dot per 32 hidden columns straight from the epilogue: tanh(fc1 x) is never stored
+          fg.rowdot_w = pool->w2;
+          fg.rowdot_out = t;
+          fg.ldrd = n_ep;
+        }
+        XNRS_TRY(launch_gemm_f32(fg, stream));
       }
       AdditivePoolArgs pa{};
-      pa.t = t;
+      pa.t = rowdot ? nullptr : t;
+      pa.epart = rowdot ? t : nullptr;
+      pa.n_epart = n_ep;
       pa.w2 = pool->w2;
       pa.b2 = pool->b2;
       pa.mask = cm;
@@ -679,12 +700,22 @@ int32_t xnrs_text_encoder_fwd_unpadded(const float* x, const int32_t* ids, int64
     vals = fold ? oc : yc;
     val_ids = nullptr;
   }
+  const int n_ep = (A + 31) / 32;
+  const bool rowdot = att && fc1_rowdot_ok(x, true, pool, n_valid, D);  // as in seq_encode (bitwise equal paths)
   if (n_valid > 0) {
     ProfScope ps(3, 2.0 * n_valid * (double)D * A, stream);
-    XNRS_TRY(launch_gemm_f32(gemm1(vals, val_ids, 1, D, fc1_w, fc1_b, tc, A, n_valid, A, D, XNRS_ACT_TANH), stream));
+    GemmArgs fg = gemm1(vals, val_ids, 1, D, fc1_w, fc1_b, tc, A, n_valid, A, D, XNRS_ACT_TANH);
+    if (rowdot) {
+      fg.rowdot_w = pool->w2;
+      fg.rowdot_out = tc;
+      fg.ldrd = n_ep;
+    }
+    XNRS_TRY(launch_gemm_f32(fg, stream));
   }
   AdditivePoolArgs pa{};
-  pa.t = tc;
+  pa.t = rowdot ? nullptr : tc;
+  pa.epart = rowdot ? tc : nullptr;
+  pa.n_epart = n_ep;
   pa.w2 = pool->w2;
   pa.b2 = pool->b2;
   pa.x = vals;

@@ -81,7 +81,7 @@ constexpr unsigned BUF_OOB = 0x40000000u;
 // interleaved MFMA / load schedule gone, 3.4 VALU instructions per MFMA and 65 % matrix-pipe occupancy in the dW GEMMs
 // (profiles/r02_train_step_pmc.txt).
 template <int TM, int TN, bool A_COL, bool B_KN, bool VEC, int PIPE, int BK, bool BUF = false, int MINW = 2, bool GATH = false,
-          int KG = 2>
+          int KG = 2, bool RDOT = false>
 __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_tiles, int n_tiles_seg, int gn) {
   static_assert(!BUF || (!A_COL && !B_KN && VEC), "buffer loads are implemented for the forward layout");
   static_assert(!GATH || BUF, "the gathered-A variant keeps buffer loads for B");
@@ -532,6 +532,33 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
   const int crow = 4 * (lane >> 5);
   const bool split = gridDim.y > 1;
   float* Cout = split ? a.slabs + (int64_t)blockIdx.y * a.slab_stride : a.C;
+  if constexpr (RDOT) {
+    // fused row dots (GemmArgs::rowdot_w): v = act(acc + bias) * w[col], summed over the 32 columns of the MFMA block by
+    // a butterfly over the 32 lanes that hold them (xor 1..16 stays inside a 32-lane half); lane 0 of the half writes
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * 32 * TN + 32 * j + ccol;
+      const bool cok = col < a.Nseg;
+      const float bv = (bias && cok) ? bias[col] : 0.f;
+      const float wv = cok ? a.rowdot_w[col] : 0.f;
+      const int slot = (n0 + wn * 32 * TN + 32 * j) >> 5;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          float v = acc[i][j][e] + bv;
+          if (a.act == 1) v = fmaxf(v, 0.f);
+          else if (a.act == 2) v = tanhf(v);
+          v *= wv;
+#pragma unroll
+          for (int off = 1; off < 32; off <<= 1) v += __shfl_xor(v, off);
+          const int64_t row = m0 + wm * 32 * TM + 32 * i + (e & 3) + 8 * (e >> 2) + crow;
+          if (ccol == 0 && row < a.M && (n0 + wn * 32 * TN + 32 * j) < a.Nseg) a.rowdot_out[row * a.ldrd + slot] = v;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + wn * 32 * TN + 32 * j + ccol;
@@ -654,6 +681,14 @@ static hipError_t launch_cfg(const GemmArgs& a, bool vec, int nsplit, hipStream_
 #define XNRS_LAUNCH_GATH(MINWV)                                                                                       \
   hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, A_COL, B_KN, true, 5, 16, true, MINWV, true>), g, dim3(256), 0, stream, a, \
                      (int)m_tiles, n_tiles_seg, gn)
+  if constexpr (!A_COL && !B_KN) {
+    if (a.rowdot_out) {  // fused row dots: its own instantiation, so that the plain kernel's registers stay as they are
+      if (!vec || !buf) return hipErrorInvalidValue;
+      hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, false, false, true, 5, 16, true, 4, false, 2, true>), g, dim3(256), 0, stream, a,
+                         (int)m_tiles, n_tiles_seg, gn);
+      return hipGetLastError();
+    }
+  }
   if (!vec) XNRS_LAUNCH(false, 1, 32, false, 2);
   else if constexpr (TM == 2 && TN == 2 && !A_COL && !B_KN) {  // forward main tile: all variants are built
     if (pipe == 1 && buf) XNRS_LAUNCH(true, 1, 32, true, 2);
@@ -760,6 +795,7 @@ static Knobs read_knobs() {
   k.mha_bwd_fused = num("XNRS_MHA_BWD_FUSED", 1) != 0;
   k.gemm_dw = (int)num("XNRS_GEMM_DW", 1);
   k.fold_out = (int)num("XNRS_FOLD_OUT", 1);
+  k.fc1_rowdot = num("XNRS_FC1_ROWDOT", 1) != 0;
   k.fold_train = (int)num("XNRS_FOLD_TRAIN", 1);
   k.news_fused = (int)num("XNRS_NEWS_FUSED", 1);
   k.news_fused_npw = (int)num("XNRS_NEWS_FUSED_NPW", 0);
@@ -800,12 +836,14 @@ hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t stream, int* nsplit
   }
   if (nsplit_used) *nsplit_used = nsplit;
   if (a.colsum && !(a.a_col && a.b_kn)) return hipErrorInvalidValue;  // fused column sums: dW layout only
+  if (a.rowdot_out && (a.a_col || a.b_kn || a.nseg != 1 || nsplit != 1 || !a.rowdot_w || a.c_scatter || a.accumulate || a.aux_mode))
+    return hipErrorInvalidValue;  // fused row dots: plain forward launches only
   hipError_t e;
   const int mode = gemm_mode();
   // the split kernel has one tile shape (128x128): below one full round of workgroups the fp32 kernel with its
   // smaller tiles is faster (measured: 4099 x 260 x 300 -> 38 TF fp32 vs 22 TF split)
   const int64_t min_tiles = knobs().split_min_tiles;  // tests force the split kernel onto tiny shapes with 0
-  if (mode && !a.a_col && !a.b_kn && vec && nsplit == 1 &&
+  if (mode && !a.rowdot_out && !a.a_col && !a.b_kn && vec && nsplit == 1 &&
       ((a.M + 127) / 128) * ((a.Nseg + 127) / 128) * a.nseg >= min_tiles)
     return launch_gemm_split(a, mode == 1 ? 3 : 2, stream);
   if (!a.a_col && !a.b_kn) e = launch_layout<false, false>(a, vec, nsplit, stream);

@@ -21,6 +21,7 @@ struct Knobs {
   long long gemm_group = -1;    // XNRS_GEMM_GROUP=n column tiles per walk group (0 = plain walk); -1 = automatic
   int gemm_tile = -1;           // XNRS_GEMM_TILE=0..3 force a block tile; -1 = cost model
   long long split_min_tiles = 512;  // XNRS_GEMM_SPLIT_MIN_TILES: smallest launch the bf16-split kernel takes
+  bool fc1_rowdot = true;       // XNRS_FC1_ROWDOT=0: inference materialises tanh(fc1 x) and the pooling kernel takes the fc2 dot
   int fold_train = 1;           // XNRS_FOLD_TRAIN=0: the training forward / backward keep the per-token out-projection
   int fold_out = 1;             // XNRS_FOLD_OUT=0: inference keeps the per-token out-projection (api.hip "fold")
   int gemm_dw = 1;              // XNRS_GEMM_DW: 1 = live-row weight gradients on gemm_dw.hip, 2 = every eligible one, 0 = none
@@ -77,6 +78,13 @@ struct GemmArgs {
   // bias gradient db = sum_rows dY is a by-product of the tiles this kernel stages anyway); nullable.  The caller
   // reduces the nsplit partial rows (launch_colsum_final).
   float* colsum;
+  // forward layout, one segment, no split-K (nullable): instead of storing C, emit per row the dot products of the
+  // activated row with rowdot_w over each block of 32 columns: rowdot_out[row * ldrd + col / 32] (the additive pooler's
+  // fc2 score straight from the fc1 epilogue: tanh(fc1 x) never exists in memory).  The 32-column blocks and the
+  // butterfly order inside them do not depend on the tile shape, so every launch shape gives the same bits.
+  const float* rowdot_w;
+  float* rowdot_out;
+  int64_t ldrd;
   // split-K (deterministic slabs + ordered reduce); set by the caller via slabs/nsplit
   float* slabs;        // nullable workspace of nsplit * M * ldc floats
   int32_t nsplit;
@@ -211,7 +219,9 @@ hipError_t launch_news_fused(const NewsFusedArgs& a, hipStream_t stream);
 
 // ---------------------------------------------------------------- pooling / scoring
 struct AdditivePoolArgs {
-  const float* t;    // [n_seq*N, A] = tanh(fc1(x)) (the tanh is fused into the fc1 GEMM epilogue)
+  const float* t;    // [n_seq*N, A] = tanh(fc1(x)) (the tanh is fused into the fc1 GEMM epilogue); null with epart
+  const float* epart;  // nullable, instead of t: [n_seq*N, n_epart] partial fc2 dots per 32-column block (GemmArgs::rowdot_out)
+  int32_t n_epart;
   const float* w2;   // [A]
   const float* b2;   // [1]
   const float* mask; // [n_seq*N] or null

@@ -32,8 +32,19 @@ __global__ __launch_bounds__(256) void additive_pool_kernel(AdditivePoolArgs a) 
   const int N = csr ? (int)(a.row_off[seq + 1] - r0) : a.N;
   const float* mask = csr ? nullptr : a.mask;
 
-  // 1. scores: one wave per row, lanes stride over the hidden dimension
+  // 1. scores: one wave per row, lanes stride over the hidden dimension -- or, with the fc2 dot already taken per block
+  //    of 32 hidden columns in the fc1 GEMM's epilogue (epart), one thread per row adding the blocks in column order
   const float b2 = a.b2 ? a.b2[0] : 0.f;
+  if (a.epart) {
+    for (int i = tid; i < N; i += 256) {
+      const float* ep = a.epart + (r0 + i) * (int64_t)a.n_epart;
+      float acc = 0.f;
+      for (int s = 0; s < a.n_epart; ++s) acc += ep[s];
+      float e = expf(acc + b2);
+      if (mask) e *= mask[src * N + i];
+      s_w[i] = e;
+    }
+  } else
   for (int i = wave; i < N; i += 4) {
     const float* t = a.t + (r0 + i) * (int64_t)A;
     float acc = 0.f;
