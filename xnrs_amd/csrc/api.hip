@@ -167,7 +167,7 @@ GemmArgs gemm1(const float* A, const int32_t* ids, int gS, int64_t lda, const fl
 // training forward keeps Y (the backward needs it).  XNRS_FOLD_OUT=0 keeps the per-token out-projection.
 // The folded weight is rebuilt per call (the ABI keeps no state): a split-K product over 8 slices and a wave-per-row bias
 // kernel, ~20 us per call at D = 768 -- three short launches.  One impression (1 250 + 250 token rows, three encoder calls)
-// pays for that: 0.33 -> 0.39 ms (a single unsliced product made it 0.44); from a few thousand token rows on the fold wins,
+// pays ~0.05 ms for that (a single unsliced product cost twice as much); from a few thousand token rows on the fold wins,
 // +25 % at the benchmark batch.  The choice deliberately never depends on the batch size -- a news item's vector must not change in the last bit with the batch
 // it is encoded in (chunking, id gather, skip_empty and the padding-free path are all tested bitwise against the plain
 // path).  Knob: 0 never, anything else always.
