@@ -168,7 +168,8 @@ GemmArgs gemm1(const float* A, const int32_t* ids, int gS, int64_t lda, const fl
 // The folded weight is rebuilt per call (the ABI keeps no state): a split-K product over 8 slices and a wave-per-row bias
 // kernel, ~20 us per call at D = 768 -- three short launches.  One impression (1 250 + 250 token rows, three encoder calls)
 // pays ~0.05 ms for that (a single unsliced product cost twice as much); from a few thousand token rows on the fold wins,
-// +25 % at the benchmark batch.  The choice deliberately never depends on the batch size -- a news item's vector must not change in the last bit with the batch
+// +25 % at the benchmark batch.  The choice deliberately never depends on the batch size (only the short-title dispatch
+// below does: fused kernel or pipeline by news count) -- a news item's vector must not change in the last bit with the batch
 // it is encoded in (chunking, id gather, skip_empty and the padding-free path are all tested bitwise against the plain
 // path).  Knob: 0 never, anything else always.
 // Returns the fc1 bias to use (nullptr if there is none).
@@ -259,7 +260,8 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
   // Short sequences go through the fused kernel (below); everything else folds the out-projection behind the pooling
   const bool fused = att && additive && !train && !a_out && att->dropout_p == 0.f && gemm_mode() == 0 &&
                      knobs().news_fused && news_fused_plan(L, D, att->n_heads, A, nullptr) &&
-                     (D / att->n_heads) * att->n_heads == D && (knobs().news_fused == 2 || (L >= 26 && n_seq >= 192));
+                     (D / att->n_heads) * att->n_heads == D &&
+                     (knobs().news_fused == 2 || (L >= 26 && n_seq >= 192 && n_seq < 1536));
   const bool fold = att && additive && !fused && fold_wanted(train ? knobs().fold_train : knobs().fold_out);
   float* wf = reinterpret_cast<float*>(w + p.off_fw);
   float* bf = reinterpret_cast<float*>(w + p.off_fb);
@@ -302,10 +304,12 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
   // vectors leave the CU.  Inference only (nothing is saved for a backward), fp32 arithmetic only.
   // Dispatch (measured, tools/bench_news_fused.py at D = 320; profiles/r02_news_fused_dispatch_sweep.txt): a workgroup owns
   // news padded to 32 token rows each, so the kernel wins from ~26 tokens (<= 19 % padding) upwards and once there are
-  // enough news to fill the CUs -- with 2 news per workgroup (every weight fragment feeds 4 row tiles) from 512 news,
-  // with 1 news per workgroup (twice the workgroups, two per CU) from ~200: 1024 x 30 tokens: 326 vs 374 us for the
-  // six-launch pipeline, 28 160 x 30: 8.2 vs 9.0 ms, 256 x 30: 116 vs 151 us; 64 x 30: 112 vs 94 us, 1024 x 20: 319 vs
-  // 271 us.  XNRS_NEWS_FUSED=2 forces it for every eligible shape (tests), 0 turns it off.
+  // enough news to fill the CUs -- with 1 news per workgroup (two workgroups per CU) from ~200, with 2 news per workgroup
+  // (every weight fragment feeds 4 row tiles) from 512: 256 x 30 tokens 116 vs 149 us for the pipeline, 512 x 30: 177 vs
+  // 217 us, 1024 x 30: 325 vs 329 us.  From ~1500 news on the pipeline is ahead again since it folds the out-projection
+  // behind the pooling (fold_out_projection above; the fused kernel computes it per token): 2048 x 30: 623 vs 592 us,
+  // 28 160 x 30: 8.2 vs 7.1 ms; 64 x 30: 111 vs 104 us, 1024 x 20: 318 vs 255 us.  XNRS_NEWS_FUSED=2 forces the kernel
+  // for every eligible shape (tests), 0 turns it off.
   if (fused) {
     NewsFusedArgs f{};
     f.x = x; f.ids = ids; f.mask = m;
