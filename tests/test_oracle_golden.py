@@ -148,3 +148,31 @@ def test_d_mod_h_error_matches_reference():
     with pytest.raises(RuntimeError) as ei:
         O.multi_head_attention(torch.zeros(2, 30, 300), None, sd, 16)
     assert str(ei.value) == meta["errors"]["msg"]
+
+
+def test_out_projection_behind_the_pooling_is_exact_algebra():
+    """The identity the HIP path's fold rests on, checked on the oracle in float64:
+    pooler(att(x)) with Y = O Wo^T + bo per token  ==  Wo (sum_i a_i O_i) + bo (sum_i a_i), scores from (W1 Wo) O_i + (W1 bo + b1)
+    -- for masks with holes, an all-masked and a fully live sequence."""
+    from xnrs_amd import synth
+    torch.manual_seed(0)
+    B, S, D, h, A = 5, 13, 24, 4, 10
+    shapes = {"q_linear.weight": (D, D), "q_linear.bias": (D,), "k_linear.weight": (D, D), "k_linear.bias": (D,),
+              "v_linear.weight": (D, D), "v_linear.bias": (D,), "out.weight": (D, D), "out.bias": (D,),
+              "fc1.weight": (A, D), "fc1.bias": (A,), "fc2.weight": (1, A), "fc2.bias": (1,)}
+    sd = {k: v.double() for k, v in synth.fill_state_dict(shapes, 901).items()}
+    x = torch.randn(B, S, D, dtype=torch.float64)
+    m = (torch.rand(B, S, 1) < 0.6).double()
+    m[0] = 0
+    m[1] = 1
+    ref = O.additive_attention(O.multi_head_attention(x, m, sd, h), m, sd)  # the reference's order
+    # the attention rows BEFORE the out-projection: run the block with an identity out layer
+    eye = dict(sd, **{"out.weight": torch.eye(D, dtype=torch.float64), "out.bias": torch.zeros(D, dtype=torch.float64)})
+    o = O.multi_head_attention(x, m, eye, h)
+    wf = sd["fc1.weight"] @ sd["out.weight"]
+    bf = sd["fc1.weight"] @ sd["out.bias"] + sd["fc1.bias"]
+    po, a = O.additive_attention(o, m, {"fc1.weight": wf, "fc1.bias": bf, "fc2.weight": sd["fc2.weight"],
+                                          "fc2.bias": sd["fc2.bias"]}, return_weights=True)
+    folded = po @ sd["out.weight"].t() + a.sum(dim=1, keepdim=True) * sd["out.bias"]
+    assert (folded - ref).abs().max().item() <= 1e-12 * ref.abs().max().item()
+    assert folded[0].abs().max().item() == 0.0  # all-masked: exactly zero either way
