@@ -69,6 +69,7 @@ struct GemmArgs {
   int64_t ldaux;
   int32_t aux_mode;    // 0 none; 1: C *= (1 - aux^2) (tanh'); 2: C *= (aux > 0) (relu')
   int32_t accumulate;  // 1: C += result
+  int32_t nt_store;    // filled in by the launcher: non-temporal C stores (outputs of >= 64 MB stream past the caches)
   // bf16-split modes only (nullable): the weights of segment s pre-split into bf16 planes [3][ldp/16][Nseg][16]
   // (launch_split_weights; ldp = K rounded up to 16, zero padded) -- the kernel then loads B planes as they are
   // instead of splitting the fp32 weights again in every row tile
