@@ -176,10 +176,12 @@ GemmArgs gemm1(const float* A, const int32_t* ids, int gS, int64_t lda, const fl
 bool fold_wanted(int knob) { return knob != 0; }
 
 // the fused row dots ride on the raw-buffer-load forward kernel: 16-byte aligned operands
-bool fc1_rowdot_ok(const float* x, bool att, const xnrs_additive_params* pool, int64_t rows, int D) {
+bool fc1_rowdot_ok(const float* x, bool att, const xnrs_additive_params* pool, int D) {
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-  return knobs().fc1_rowdot && knobs().gemm_buf && gemm_mode() == 0 && pool && pool->w2 && D % 4 == 0 && al16(pool->w1) &&
-         (att || al16(x)) && rows * D * 4 <= (1ll << 30) && (int64_t)pool->hidden * D * 4 <= (1ll << 30);
+  // (rows of any count / any gather: beyond the 1-GB descriptor window or with row ids the launcher takes the
+  // pointer-gather variant of the same kernel)
+  return knobs().fc1_rowdot && knobs().gemm_buf && gemm_mode() == 0 && pool && pool->w2 && D % 4 == 0 && D >= 4 &&
+         al16(pool->w1) && (att || al16(x)) && (int64_t)pool->hidden * D * 4 <= (1ll << 30);
 }
 
 
@@ -270,9 +272,8 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
   // inference, fp32 GEMM mode, 16-byte-aligned shapes the buffer-load kernel serves, no gathered rows: the pooler's fc2
   // dot is taken in the fc1 epilogue (GemmArgs::rowdot_out; the T region then holds A/32 partial dots per row)
   const int n_ep = (A + 31) / 32;
-  // (attention towers only: there the fc1 input is the dense O / Y image whatever the input path -- ids, padded,
-  // unpadded --, so all of them take the same route and stay bitwise equal)
-  const bool rowdot = att && additive && !train && !fused && fc1_rowdot_ok(x, true, pool, p.chunk * (int64_t)L, D);
+  // (every input path -- dense rows, id gather, padding-free -- takes it, so they stay bitwise equal)
+  const bool rowdot = additive && !train && !fused && fc1_rowdot_ok(x, att != nullptr, pool, D);
   const float* fc1_w = additive ? pool->w1 : nullptr;
   const float* fc1_b = additive ? pool->b1 : nullptr;
   if (fold) {
@@ -705,7 +706,7 @@ int32_t xnrs_text_encoder_fwd_unpadded(const float* x, const int32_t* ids, int64
     val_ids = nullptr;
   }
   const int n_ep = (A + 31) / 32;
-  const bool rowdot = att && fc1_rowdot_ok(x, true, pool, n_valid, D);  // as in seq_encode (bitwise equal paths)
+  const bool rowdot = fc1_rowdot_ok(x, att != nullptr, pool, D);  // as in seq_encode (bitwise equal paths)
   if (n_valid > 0) {
     ProfScope ps(3, 2.0 * n_valid * (double)D * A, stream);
     GemmArgs fg = gemm1(vals, val_ids, 1, D, fc1_w, fc1_b, tc, A, n_valid, A, D, XNRS_ACT_TANH);

@@ -684,9 +684,13 @@ static hipError_t launch_cfg(const GemmArgs& a, bool vec, int nsplit, hipStream_
                      (int)m_tiles, n_tiles_seg, gn)
   if constexpr (!A_COL && !B_KN) {
     if (a.rowdot_out) {  // fused row dots: its own instantiation, so that the plain kernel's registers stay as they are
-      if (!vec || !buf) return hipErrorInvalidValue;
-      hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, false, false, true, 5, 16, true, 4, false, 2, true>), g, dim3(256), 0, stream, a,
-                         (int)m_tiles, n_tiles_seg, gn);
+      if (!vec || !(buf || gath)) return hipErrorInvalidValue;
+      if (buf)
+        hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, false, false, true, 5, 16, true, 4, false, 2, true>), g, dim3(256), 0, stream,
+                           a, (int)m_tiles, n_tiles_seg, gn);
+      else  // gathered A rows (a news table, the compact rows of the padding-free path) or an A beyond 1 GB
+        hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, false, false, true, 5, 16, true, 4, true, 2, true>), g, dim3(256), 0, stream,
+                           a, (int)m_tiles, n_tiles_seg, gn);
       return hipGetLastError();
     }
   }
