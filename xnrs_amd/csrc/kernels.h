@@ -177,6 +177,20 @@ hipError_t launch_mha_bwd(const MhaBwdArgs& a, hipStream_t stream);
 // hardware exp2 path: <= ~2e-7 relative per element against torch's division/expf -- far inside the 1e-4
 // parity bar -- and it takes the softmax from ~45 to ~10 VALU instructions per element (the attention
 // kernel was VALU-bound, not MFMA-bound).
+// (sequence, head) pair of workgroup L out of W = n_seq * n_heads, XCD-aware: the dispatcher deals workgroup L to XCD L % 8.
+// The heads of ONE sequence go to one XCD, next to each other in time (a head row is 4 d_k bytes, so neighbouring heads
+// share 128-B lines that two L2s would otherwise both fetch), while the SEQUENCES are dealt round-robin over the XCDs:
+// work per sequence varies with the mask (the backward skips masked query tiles, unpadded queries are fewer), and a
+// contiguous range of sequences per XCD -- all of one user's empty history slots -- left some XCDs 30 % more work.
+__device__ __forceinline__ int64_t xcd_pair(int64_t L, int64_t W, int n_heads) {
+  const int64_t n_seq = W / n_heads;
+  const int64_t full = (n_seq >> 3) << 3;           // sequences dealt in whole rounds of 8
+  const int64_t per = (full >> 3) * n_heads;        // workgroups per XCD that serve them
+  const int64_t x = L & 7, q = L >> 3;
+  if (q < per) return ((q / n_heads) * 8 + x) * n_heads + (q % n_heads);
+  return full * n_heads + (q - per) * 8 + x;       // the last n_seq % 8 sequences: plain round-robin
+}
+
 __device__ __forceinline__ float attn_exp(float x) { return __expf(x); }
 
 // counter-based RNG for attention dropout (training mode only): splitmix64 finaliser on

@@ -312,12 +312,8 @@ __global__ __launch_bounds__(256) void mha_bwd_fused_kernel(MhaBwdArgs a) {
   __shared__ __attribute__((aligned(16))) float Ps[BWD_PBUF][4][16 * BWD_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
-  // XCD-contiguous pair order (as mha_core_pair_kernel): the heads of one sequence share 128-B lines of Q / K / V / dO
-  int64_t pair;
-  {
-    const int64_t L = blockIdx.x, W = gridDim.x, x = L & 7, per = W >> 3, rm = W & 7;
-    pair = per * x + (x < rm ? x : rm) + (L >> 3);
-  }
+  // XCD-aware pair order (kernels.h xcd_pair): heads of a sequence on one XCD, sequences round-robin over the XCDs
+  const int64_t pair = xcd_pair(blockIdx.x, gridDim.x, a.n_heads);
   const int hd = (int)(pair % a.n_heads);
   const int64_t seq = pair / a.n_heads;
   const int S = a.S, dk = a.d_k;
