@@ -322,17 +322,25 @@ __global__ __launch_bounds__(256) void mha_bwd_fused_kernel(MhaBwdArgs a) {
   const int QT = (S + 15) >> 4;  // query tiles = key tiles
   const bool active = wave < QT;
 
-  // ---- stage Q and dO of this head (rows >= S and features >= d_k as zeros)
+  // ---- stage Q and dO of this head (rows >= S and features >= d_k as zeros); delta = rowsum(dO * O) of the head is
+  // taken on the way (a separate pass over dO and O -- mha_delta_kernel -- read 590 MB per 96 000-row encode for it):
+  // one partial per 16-byte chunk into LDS (the dS transpose tiles are idle until the first query tile), summed per row
+  // in chunk order below
   constexpr int NCH = NFB * 4;
+  __shared__ float s_delta[64];
+  float* s_dpart = &Ts[0][0];  // 64 x NCH <= 1024 floats of the 1280
+  static_assert(64 * NFB * 4 <= 4 * 16 * BWD_TLD, "delta partials must fit the transpose tiles");
   for (int idx = tid; idx < 64 * NCH; idx += 256) {
     const int row = idx / NCH, f0 = (idx - row * NCH) * 4;
-    f32x4 qv = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+    f32x4 qv = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f}, ov = {0.f, 0.f, 0.f, 0.f};
     if (row < S && f0 < dk) {
       qv = *reinterpret_cast<const f32x4*>(a.q + (row0 + row) * a.ld + hoff + f0);
       dv = *reinterpret_cast<const f32x4*>(a.d_o + (row0 + row) * a.lddo + hoff + f0);
+      ov = *reinterpret_cast<const f32x4*>(a.o + (row0 + row) * a.ldo + hoff + f0);
     }
     *reinterpret_cast<f32x4*>(&Qs[row * BWD_LD + f0]) = qv;
     *reinterpret_cast<f32x4*>(&Ds[row * BWD_LD + f0]) = dv;
+    s_dpart[idx] = fmaf(dv[3], ov[3], fmaf(dv[2], ov[2], fmaf(dv[1], ov[1], dv[0] * ov[0])));
   }
   // ---- this wave's key tile in registers
   const int key = wave * 16 + c;
@@ -363,6 +371,13 @@ __global__ __launch_bounds__(256) void mha_bwd_fused_kernel(MhaBwdArgs a) {
   for (int t = 0; t < NFB; ++t) {
     dkT[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     dvT[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float acc = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) acc += s_dpart[tid * NCH + ch];
+    s_delta[tid] = acc;
   }
   __syncthreads();
 
@@ -404,7 +419,7 @@ __global__ __launch_bounds__(256) void mha_bwd_fused_kernel(MhaBwdArgs a) {
           const float mq = a.mask ? a.mask[mrow + query] : 1.f;
           const float mx = a.stats[2 * (sbase + query)];
           const float sum = a.stats[2 * (sbase + query) + 1];
-          const float delta = a.delta[sbase + query];
+          const float delta = s_delta[query];
           float sv = s[r] * inv_sq;
           if (mq == 0.f) sv = -1e9f;
           const float p = attn_exp(sv - mx) * (1.f / sum);
@@ -498,12 +513,16 @@ hipError_t launch_mha_bwd(const MhaBwdArgs& a, hipStream_t stream) {
                    al16(a.v) && al16(a.d_o) && al16(a.dq) && al16(a.dk) && al16(a.dv);
   if (a.n_heads * a.d_k > 2048) return hipErrorInvalidValue;
   const int64_t n_rows = a.n_seq * a.S;
-  const unsigned dgrid = (unsigned)(n_rows < 65536 ? n_rows : 65536);
-  hipLaunchKernelGGL(mha_delta_kernel, dim3(dgrid), dim3(256), 0, stream, a, n_rows);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
+  hipError_t e = hipSuccess;
   const int KT = (a.S + 15) / 16;
-  if (vec && a.S <= 64 && a.d_k <= 64 && knobs().mha_bwd_fused) {  // development knob for A/B runs; default on
+  const bool fused = vec && a.S <= 64 && a.d_k <= 64 && a.ldo % 4 == 0 && al16(a.o) && knobs().mha_bwd_fused;
+  if (!fused) {  // the fused kernel takes delta = rowsum(dO * O) while it stages dO
+    const unsigned dgrid = (unsigned)(n_rows < 65536 ? n_rows : 65536);
+    hipLaunchKernelGGL(mha_delta_kernel, dim3(dgrid), dim3(256), 0, stream, a, n_rows);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  if (fused) {  // (knobs().mha_bwd_fused: development knob for A/B runs; default on)
     const int64_t n_pairs = a.n_seq * a.n_heads;
     if (n_pairs > 0x7fffffffLL) return hipErrorInvalidValue;
     const dim3 fgrid((unsigned)n_pairs);
