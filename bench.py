@@ -282,10 +282,24 @@ def news_only_extra(device, steps=20, warmup=10):
     return out
 
 
+def other_model_flops(name, H, C, S=50, D=768, A=256, E=256):
+    """Executed = algorithmic FLOPs per impression of the additive-only models (SURVEY.md section 8d formulas):
+    StandardRec (standard_model.py:8-37): additive news tower + MLP head, additive user tower + MLP head;
+    NAML (naml.py:61-112): two additive text towers + two 16->E category views + a 4-view additive pooler per news,
+    additive user attention."""
+    add = lambda n, d: 2 * n * d * A + 2 * n * A + 2 * n * d  # noqa: E731  fc1 + fc2 + weighted sum over n rows of width d
+    news = add(S, D) + 2 * D * E + 2 * E * E
+    if name == "standard":
+        return (H + C) * news + add(H, E) + 4 * E * E + 2 * C * E
+    return (H + C) * (2 * news + 2 * (2 * 16 * E) + add(4, E)) + add(H, E) + 2 * C * E
+
+
 def other_models_extra(device, steps=5, warmup=2):
-    """BASELINE configs[3]/[4] forward throughput on one GPU: StandardRec (the CL bi-encoder,
-    config/mind_small_CL.yml: additive-only towers + heads) and NAML (title + abstract + category views),
-    B=512 impressions, H=25, C=5, S=50, D=768."""
+    """BASELINE configs[3]/[4] forward on one GPU: StandardRec (the CL bi-encoder, config/mind_small_CL.yml: additive-only
+    towers + heads) and NAML (title + abstract + category views), B=512 impressions, H=25, C=5, S=50, D=768.  Per model:
+    throughput, executed FLOPs against the fp32 matrix peak, the dominant kernel (fc1 + tanh + fc2-dot GEMM of the
+    additive pooler) timed with hipEvents, and a parity spot-check of 4 impressions against the CPU oracle."""
+    from oracle import xnrs_oracle as O
     out = {}
     B, H, C, S, D = 512, 25, 5, 50, 768
     gen = torch.Generator(device=device)
@@ -294,7 +308,8 @@ def other_models_extra(device, steps=5, warmup=2):
         c = dict(model=name, E=256, bias=False, h=16, D=D, H=H, S=S)
         model = make_model(Cfg(synth.model_cfg(c)))
         shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-        model.load_state_dict(synth.fill_state_dict(shapes, 99))
+        sd = synth.fill_state_dict(shapes, 99)
+        model.load_state_dict(sd)
         model = model.eval().to(device)
 
         def toks(n):
@@ -310,7 +325,35 @@ def other_models_extra(device, steps=5, warmup=2):
         batch = {"user_features": {"history": hist, "other": {}}, "candidate_features": cand}
         fn = lambda: model(batch)  # noqa: E731
         dt = timed(fn, steps, warmup, False) / steps
-        out[name] = dict(impressions_per_s=B / dt, ms=dt * 1e3)
+        hip.profile_enable(0x3F)
+        r = fn()
+        torch.cuda.synchronize()
+        st = hip.profile_read()
+        hip.profile_enable(0)
+        assert torch.isfinite(r).all(), name
+        fl = other_model_flops(name, H, C) * B
+        f_ms, f_n, f_fl = st["fc1_tanh_gemm"]
+
+        def cut(v):
+            if isinstance(v, torch.Tensor):
+                return v[:4].cpu()
+            if isinstance(v, dict):
+                return {k: cut(x) for k, x in v.items()}
+            return tuple(cut(x) for x in v) if isinstance(v, tuple) else v
+        small = cut(batch)
+        ref = O.naml_forward(small, sd) if name == "NAML" else O.parent_forward(
+            small["user_features"]["history"]["title_emb"], small["candidate_features"]["title_emb"], sd, 16)
+        err = (r[:4].cpu().double() - ref.double()).abs().max().item() / ref.abs().max().item()
+        assert err <= 1e-4, (name, err)
+        out[name] = dict(impressions_per_s=B / dt, ms=dt * 1e3, executed_tflops=fl / dt / 1e12,
+                         frac_fp32_mfma=fl / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                         alg_gbs=B * (H + C) * (2 if name == "NAML" else 1) * (4 * S * D + 4 * S) / dt / 1e9,
+                         stage_ms_per_step={k: round(v[0], 3) for k, v in st.items() if v[1]},
+                         roofline={"bound": "mfma", "kernel": "gemm_f32_kernel<...RDOT> (additive pooler: fc1 + tanh + fc2 dot)",
+                                   "achieved": (f_fl / (f_ms * 1e-3) / 1e12) if f_ms > 0 else 0.0, "peak": FP32_MFMA_PEAK_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": (f_fl / (f_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS) if f_ms > 0 else 0.0,
+                                   "launches_timed": f_n, "avg_launch_ms": f_ms / max(f_n, 1), "traffic": None},
+                         parity_max_rel_err_vs_cpu=err)
     return out
 
 
@@ -611,19 +654,25 @@ def train_scaling(args, device, rank, world, dist_on):
     labels = torch.randint(0, 6, (w["B"],), device=device, generator=gen)
     batch = {"user_features": {"history": {"title_emb": hist}, "other": {}}, "candidate_features": {"title_emb": cand}}
     n_global = w["B"] * (world if dist_on else 1)
+    # once per run: the shard layout (fixed per-rank batch -> no communication) and the persistent gradient bucket
+    layout = D.ShardLayout.uniform(w["B"]) if dist_on else None
+    bucket = D.GradBucket(model.parameters()) if dist_on else None
 
     def fn():
-        opt.zero_grad()
+        if dist_on:
+            bucket.zero_grad()
+        else:
+            opt.zero_grad()
         r, u, _ = model(batch, return_embeddings=True)
         rec = torch.nn.functional.mse_loss(torch.relu(r), targets)
-        if dist_on:
-            cl = infonce(D.all_gather_rows(u.squeeze(1)), D.all_gather_labels(labels), 0.08)
-            loss = D.global_train_loss(rec, w["B"], n_global, cl, 0.1)
+        if dist_on:  # two collectives, no host sync: [embedding | label bits] all-gather + flat gradient all-reduce
+            ue_all, lab_all = D.gather_embeddings_and_labels(u.squeeze(1), labels, layout)
+            loss = D.global_train_loss(rec, w["B"], n_global, infonce(ue_all, lab_all, 0.08), 0.1)
         else:
             loss = rec + 0.1 * infonce(u.squeeze(1), labels, 0.08)
         loss.backward()
         if dist_on:
-            D.allreduce_gradients(model.parameters())
+            bucket.allreduce()
         opt.step()
         return loss
     dt = timed(fn, args.steps, args.warmup, dist_on)
@@ -634,8 +683,9 @@ def train_scaling(args, device, rank, world, dist_on):
             "vs_baseline": None, "dtype": GEMM_MODES[args.gemm_mode][0], "data": "synthetic",
             "config": {"workload": f"{args.train} grad step, 64 impressions per GPU (H=25, C=5, S=50, D=768), global in-batch "
                                    "InfoNCE (lambda 0.1, tau 0.08), attention dropout 0.1",
-                       "parallelism": f"impressions sharded over {n_gpus} GPU(s); all-gather of (64, 256) user embeddings + "
-                                      "one flat fp32 gradient all-reduce per step"},
+                       "parallelism": f"impressions sharded over {n_gpus} GPU(s); per step ONE all-gather of (64, 256+1) [user "
+                                      "embedding | label bits] + ONE flat fp32 gradient all-reduce in a persistent bucket, no "
+                                      "host sync"},
             "loss_finite": bool(torch.isfinite(fn()).item())}
 
 

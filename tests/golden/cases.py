@@ -168,6 +168,43 @@ def data_corpus(c=None):
     return news_feat, sessions
 
 
+# NAML / LSTUR-news by table row (BASELINE configs[4]): a corpus with title + abstract tokens and both category columns in
+# the reference's in-memory format; the REAL NewsRecDataset materialises the eval items (dataset.py:48-163) and the REAL
+# NAML / LSTURNewsEncoder score them (make_golden.py: naml_data_cases) -- the id path over a NewsStore must reproduce that.
+NAML_DATA = dict(n_news=24, S=6, D=32, E=16, l_hist=5, seed=620, model_seed=621)
+NAML_SESSIONS = [(2, 1, 3), (5, 2, 4), (9, 1, 6), (1, 2, 2), (7, 1, 8)]
+
+
+def naml_corpus(c=None):
+    from xnrs_amd import synth
+    c = c or NAML_DATA
+    rng = synth.rng_for(c["seed"])
+    news_feat = {}
+    for i in range(c["n_news"]):
+        feats = {}
+        for name, S in (("title_emb", c["S"]), ("abstract_emb", c["S"])):  # one l_seq for every text feature (dataset.py:80-84)
+            L = int(rng.integers(1, S + 1))
+            if name == "abstract_emb" and i % 7 == 3:
+                L = 0  # a news without an abstract: all-masked view
+            emb = rng.standard_normal((1, S, c["D"])).astype(np.float32)
+            feats[name] = (emb, (np.arange(S)[None, :] < L).astype(np.float32))
+        feats["category_index"] = int(rng.integers(1, 20))
+        feats["subcategory_index"] = int(rng.integers(1, 301))
+        news_feat[f"N{i}"] = feats
+    ids = list(news_feat)
+    sessions = []
+    for s_i, (nh, npos, nneg) in enumerate(NAML_SESSIONS):
+        pick = lambda k: [ids[int(j)] for j in rng.integers(0, len(ids), size=k)]  # noqa: E731
+        sessions.append({"history": pick(nh), "positives": pick(npos), "negatives": pick(nneg),
+                         "main_theme": f"theme{s_i % 3}", "main_category": "news", "user_index": s_i})
+    return news_feat, sessions
+
+
+def naml_data_cfg(c=None):
+    c = c or NAML_DATA
+    return model_cfg(dict(model="NAML", E=c["E"], bias=False, h=4, D=c["D"], H=c["l_hist"], S=c["S"]))
+
+
 METRIC_CASES = {
     "plain": ([1, 0, 0, 1, 0, 0, 0], [0.9, 0.1, 0.5, 0.4, 0.45, 0.0, 0.3]),
     "relu_ties": ([1, 0, 0, 0, 1, 0], [0.7, 0.0, 0.0, 0.2, 0.0, 0.0]),

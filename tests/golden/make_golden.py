@@ -226,6 +226,34 @@ def data_cases():
     return out
 
 
+def naml_data_cases():
+    """The REAL NewsRecDataset (eval mode: history truncation / zero padding, all positives then all negatives, the two
+    category columns through stack_scalars) feeding the REAL NAML and LSTURNewsEncoder: scores, user embeddings and
+    LSTUR news vectors per session.  Outputs only -- corpus, weights and sessions regenerate from cases.NAML_DATA."""
+    from xnrs.data.dataset import NewsRecDataset
+    from xnrs.utils import add_batch_dim_
+    c = cases.NAML_DATA
+    news_feat, sessions = cases.naml_corpus(c)
+    ds = NewsRecDataset(uds=sessions, news_feat=news_feat, mode="eval", n_negatives=None, l_seq=c["S"], l_hist=c["l_hist"],
+                        text_features=["title_emb", "abstract_emb"], catg_features=["category_index", "subcategory_index"])
+    cfg = Cfg(cases.naml_data_cfg(c))
+    naml = load(make_model(cfg), c["model_seed"])
+    lcfg = Cfg(dict(cfg, catg_features=["category_index", "subcategory_index"]))
+    lstur = load(LSTURNewsEncoder(lcfg), c["model_seed"] + 1)
+    out = {}
+    for i in range(len(sessions)):
+        it = ds[i]
+        batch = {"user_features": it["user_features"], "candidate_features": it["candidate_features"]}
+        add_batch_dim_(batch)
+        with torch.no_grad():
+            out[f"naml_ids/s{i}/r"] = npy(naml(batch))
+            out[f"naml_ids/s{i}/ue"] = npy(naml.get_user_embeddings(batch))
+            hist = batch["user_features"]["history"]
+            e, m = lstur(hist["title_emb"], hist["category_index"], hist["subcategory_index"])
+            out[f"lstur_ids/s{i}/e"], out[f"lstur_ids/s{i}/m"] = npy(e), npy(m)
+    return out
+
+
 def shipped_config_cases():
     """The reference's make_model on its own shipped YAMLs (config/mind_small_{NRMS,CL,NAML}.yml): the flat cfg keys the
     model constructors read (data: hyper-parameters) and the resulting state_dict key -> shape map + parameter count.
@@ -270,6 +298,7 @@ def main():
         "lstur": lstur_case(),
         "grads": grad_cases(),
         "data": data_cases(),
+        "naml_ids": naml_data_cases(),
     }
     for g, d in groups.items():
         np.savez_compressed(os.path.join(HERE, f"{g}.npz"), **d)

@@ -88,17 +88,20 @@ def test_one_rank_rccl_train_step_equals_plain_step():
         model = make_model(cfg).to(DEV).eval()
         if distributed:
             D.broadcast_parameters(model)
+            bucket = D.GradBucket(model.parameters())  # .grad = views of one flat buffer
+            bucket.zero_grad()
         r, u, _ = model.forward_ids(store.x, store.m, hist, cand, return_embeddings=True)
         rec = torch.nn.functional.mse_loss(torch.relu(r), targets)
-        if distributed:
-            ue = D.all_gather_rows(u.squeeze(1))
-            lab = D.all_gather_labels(labels)
+        if distributed:  # the step's two collectives over RCCL: [embedding | label bits] all-gather, flat all-reduce
+            ue, lab = D.gather_embeddings_and_labels(u.squeeze(1), labels, D.ShardLayout.uniform(r.shape[0]))
+            assert torch.equal(lab, labels)
             loss = D.global_train_loss(rec, r.shape[0], r.shape[0], contrastive_loss(ue, lab, 0.08), 0.1)
         else:
             loss = rec + 0.1 * contrastive_loss(u.squeeze(1), labels, 0.08)
         loss.backward()
         if distributed:
-            D.allreduce_gradients(model.parameters())
+            bucket.allreduce()
+            assert bucket._attached()
         return loss.detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
 
     l0, g0 = step(False)

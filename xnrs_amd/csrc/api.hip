@@ -259,11 +259,28 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
                     !(ids && !live_src_rows);
   const int32_t* lvx = live ? (ids ? live_src_rows : live_rows) : nullptr;  // rows of x (table rows with ids)
 
-  // Short sequences go through the fused kernel (below); everything else folds the out-projection behind the pooling
-  const bool fused = att && additive && !train && !a_out && att->dropout_p == 0.f && gemm_mode() == 0 &&
-                     knobs().news_fused && news_fused_plan(L, D, att->n_heads, A, nullptr) &&
-                     (D / att->n_heads) * att->n_heads == D &&
-                     (knobs().news_fused == 2 || (L >= 26 && n_seq >= 192 && n_seq < 1536));
+  // Short sequences go through the fused kernel (below); everything else folds the out-projection behind the pooling.
+  // The predicate covers EVERY precondition of the launch (shape, 16-byte aligned operands, 160 KB of dynamic LDS on the
+  // current device: news_fused_ready), so a batch the kernel cannot take runs on the pipeline instead of failing.
+  NewsFusedArgs f{};
+  bool fused = att && additive && !train && !a_out && att->dropout_p == 0.f && gemm_mode() == 0 &&
+               knobs().news_fused && news_fused_plan(L, D, att->n_heads, A, nullptr) &&
+               (D / att->n_heads) * att->n_heads == D &&
+               (knobs().news_fused == 2 || (L >= 26 && n_seq >= 192 && n_seq < 1536));
+  if (fused) {
+    f.x = x; f.ids = ids; f.mask = m;
+    f.wq = att->wq; f.bq = att->bq; f.wk = att->wk; f.bk = att->bk; f.wv = att->wv; f.bv = att->bv;
+    f.wo = att->wo; f.bo = att->bo;
+    f.w1 = pool->w1; f.b1 = pool->b1; f.w2 = pool->w2; f.b2 = pool->b2;
+    f.img = reinterpret_cast<float*>(w + p.off_nf);
+    f.p = head ? pb : y;
+    f.ldp = D;
+    f.hm = m ? hm : nullptr;
+    f.n_seq = n_seq;
+    f.S = L; f.D = D; f.n_heads = att->n_heads; f.d_k = D / att->n_heads; f.A = A; f.scaled = att->scaled;
+    f.npw = knobs().news_fused_npw ? knobs().news_fused_npw : (n_seq < 512 ? 1 : 2);
+    fused = p.off_nf != 0 && news_fused_ready(f);
+  }
   const bool fold = att && additive && !fused && fold_wanted(train ? knobs().fold_train : knobs().fold_out);
   float* wf = reinterpret_cast<float*>(w + p.off_fw);
   float* bf = reinterpret_cast<float*>(w + p.off_fb);
@@ -312,18 +329,6 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
   // 28 160 x 30: 8.2 vs 7.1 ms; 64 x 30: 111 vs 104 us, 1024 x 20: 318 vs 255 us.  XNRS_NEWS_FUSED=2 forces the kernel
   // for every eligible shape (tests), 0 turns it off.
   if (fused) {
-    NewsFusedArgs f{};
-    f.x = x; f.ids = ids; f.mask = m;
-    f.wq = att->wq; f.bq = att->bq; f.wk = att->wk; f.bk = att->bk; f.wv = att->wv; f.bv = att->bv;
-    f.wo = att->wo; f.bo = att->bo;
-    f.w1 = pool->w1; f.b1 = pool->b1; f.w2 = pool->w2; f.b2 = pool->b2;
-    f.img = reinterpret_cast<float*>(w + p.off_nf);
-    f.p = head ? pb : y;
-    f.ldp = D;
-    f.hm = m ? hm : nullptr;
-    f.n_seq = n_seq;
-    f.S = L; f.D = D; f.n_heads = att->n_heads; f.d_k = D / att->n_heads; f.A = A; f.scaled = att->scaled;
-    f.npw = knobs().news_fused_npw ? knobs().news_fused_npw : (n_seq < 512 ? 1 : 2);
     const double fl = (double)n_seq * (8.0 * L * D * D + 4.0 * L * L * D + 2.0 * L * D * A + 2.0 * L * (A + D));
     ProfScope ps(6, fl, stream);
     XNRS_TRY(launch_news_fused(f, stream));

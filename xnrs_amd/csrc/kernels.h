@@ -230,6 +230,9 @@ struct NewsFusedPlan {
 // does the fused kernel cover this shape (and with which plan)?
 bool news_fused_plan(int S, int D, int n_heads, int A, NewsFusedPlan* plan, int npw = 2);
 size_t news_fused_img_bound_bytes(int S, int D, int A);  // >= img_bytes for every n_heads; 0: no head count is eligible
+// the launch's remaining preconditions (16-byte aligned operands, 160 KB of dynamic LDS granted on the CURRENT device);
+// false = use the GEMM pipeline for this call
+bool news_fused_ready(const NewsFusedArgs& a);
 hipError_t launch_news_fused(const NewsFusedArgs& a, hipStream_t stream);
 
 // ---------------------------------------------------------------- pooling / scoring

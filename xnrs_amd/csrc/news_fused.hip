@@ -659,14 +659,58 @@ size_t news_fused_img_bound_bytes(int S, int D, int A) {
   return NfImg{ng, (D + 15) / 16, 16}.total() * sizeof(float);
 }
 
+namespace {
+// One instantiation per head width (d_k / 4 = 1 .. 8) and news count; each needs its dynamic-LDS limit raised once PER
+// DEVICE (hipFuncSetAttribute acts on the current device's code object): the result is cached per (device, instantiation).
+constexpr int NF_MAX_DEV = 64;
+std::mutex g_attr_mu;
+signed char g_attr_state[NF_MAX_DEV][8][2];  // 0 unknown, 1 ok, -1 refused (e.g. a part with less than 160 KB of LDS)
+
+template <int Q, int N>
+bool nf_attr_ok(int dev) {
+  if (dev < 0 || dev >= NF_MAX_DEV) return false;
+  std::lock_guard<std::mutex> lk(g_attr_mu);
+  signed char& st = g_attr_state[dev][Q - 1][N - 1];
+  if (st == 0) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&news_fused_kernel<Q, N>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) (void)hipGetLastError();  // a refusal is an answer, not a sticky error of the caller's stream
+    st = e == hipSuccess ? 1 : -1;
+  }
+  return st == 1;
+}
+
+bool nf_attr_ok(int q, int npw, int dev) {
+#define NF_A(Q) \
+  case Q: return npw == 1 ? nf_attr_ok<Q, 1>(dev) : nf_attr_ok<Q, 2>(dev);
+  switch (q) {
+    NF_A(1) NF_A(2) NF_A(3) NF_A(4) NF_A(5) NF_A(6) NF_A(7) NF_A(8)
+    default: return false;
+  }
+#undef NF_A
+}
+}  // namespace
+
+// Everything launch_news_fused needs beyond the shape (news_fused_plan): 16-byte aligned operands and a device that
+// grants the kernel its 160 KB of dynamic LDS.  The dispatcher asks BEFORE it commits to the fused kernel, so a batch
+// this kernel cannot take runs on the GEMM pipeline instead of failing.
+bool news_fused_ready(const NewsFusedArgs& a) {
+  NewsFusedPlan p;
+  const int npw = a.npw == 1 ? 1 : 2;
+  if (!news_fused_plan(a.S, a.D, a.n_heads, a.A, &p, npw) || a.d_k * a.n_heads != a.D) return false;
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (!al16(a.x) || !al16(a.wq) || !al16(a.wk) || !al16(a.wv) || !al16(a.wo) || !al16(a.w1) || !a.img || !al16(a.img))
+    return false;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  return nf_attr_ok(a.d_k / 4, npw, dev);
+}
+
 hipError_t launch_news_fused(const NewsFusedArgs& a, hipStream_t stream) {
   if (a.n_seq <= 0) return hipSuccess;
   NewsFusedPlan p;
   const int npw = a.npw == 1 ? 1 : 2;
-  if (!news_fused_plan(a.S, a.D, a.n_heads, a.A, &p, npw) || a.d_k * a.n_heads != a.D) return hipErrorInvalidValue;
-  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  if (!al16(a.x) || !al16(a.wq) || !al16(a.wk) || !al16(a.wv) || !al16(a.wo) || !al16(a.w1) || !a.img || !al16(a.img))
-    return hipErrorInvalidValue;
+  if (!news_fused_ready(a) || !news_fused_plan(a.S, a.D, a.n_heads, a.A, &p, npw)) return hipErrorInvalidValue;
   // prologue: the weights in MFMA fragment order (see the file header); ~2 MB, rebuilt per call -- the ABI keeps no state
   const NfImg im{p.n_groups, p.nk, p.nkc};
   const size_t n4 = im.total() / 4;
@@ -675,16 +719,8 @@ hipError_t launch_news_fused(const NewsFusedArgs& a, hipStream_t stream) {
   if (pe != hipSuccess) return pe;
   const int64_t grid = (a.n_seq + p.npw - 1) / p.npw;
   if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  // one instantiation per head width (d_k / 4 = 1 .. 8) and news count; each needs its dynamic-LDS limit raised once
-  static std::once_flag once[8][2];
-  static hipError_t attr_rc[8][2];
   hipError_t rc = hipErrorInvalidValue;
 #define NF_LAUNCH(Q, N)                                                                                                    \
-  std::call_once(once[Q - 1][N - 1], [] {                                                                                  \
-    attr_rc[Q - 1][N - 1] = hipFuncSetAttribute(reinterpret_cast<const void*>(&news_fused_kernel<Q, N>),                   \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                   \
-  });                                                                                                                      \
-  if (attr_rc[Q - 1][N - 1] != hipSuccess) return attr_rc[Q - 1][N - 1];                                                   \
   hipLaunchKernelGGL((news_fused_kernel<Q, N>), dim3((unsigned)grid), dim3(NF_THREADS), p.lds_bytes, stream, a, im, a.img, \
                      p.hg, p.lq, p.ly);                                                                                    \
   rc = hipGetLastError();

@@ -21,91 +21,231 @@ import torch
 
 from . import hip
 
-MAGIC = "xnrs_amd.newsstore.v1"
+MAGIC = "xnrs_amd.newsstore.v2"
+_MAGIC_V1 = "xnrs_amd.newsstore.v1"  # single text feature; still readable
 
 
 class NewsStore:
-    def __init__(self, x: torch.Tensor, m: torch.Tensor, ids: List, columns: Optional[Dict[str, torch.Tensor]] = None):
+    """x, m: the PRIMARY text feature's token table [n_rows,S,D] / mask [n_rows,S] (`feature`, 'title_emb' by default);
+    `texts`: further text features over the same rows ({'abstract_emb': (x, m)}: NAML's second view, naml.py:76-80);
+    `columns`: int32 categorical features per row ({'category_index': ...}, dataset.py:111-124)."""
+
+    def __init__(self, x: torch.Tensor, m: torch.Tensor, ids: List, columns: Optional[Dict[str, torch.Tensor]] = None,
+                 texts: Optional[Dict[str, tuple]] = None, feature: str = "title_emb"):
         assert x.dim() == 3 and m.shape == x.shape[:2]
         self.x, self.m = x, m  # row 0 = empty slot
         self.ids = list(ids)   # news id of row i+1
         self.index = {nid: i + 1 for i, nid in enumerate(self.ids)}
         self.columns = columns or {}
+        self.feature = feature
+        self.texts = dict(texts or {})
+        for k, (tx, tm) in self.texts.items():
+            assert tx.dim() == 3 and tm.shape == tx.shape[:2] and tx.shape[0] == x.shape[0], k
         self.pad_row = 0
+
+    @property
+    def n_rows(self) -> int:
+        return self.x.shape[0]
+
+    def text(self, feature: str):
+        """(x, m) of a text feature."""
+        if feature == self.feature:
+            return self.x, self.m
+        if feature not in self.texts:
+            raise KeyError(f"news store has no text feature {feature!r} (has: {[self.feature] + sorted(self.texts)})")
+        return self.texts[feature]
+
+    def column(self, name: str) -> torch.Tensor:
+        if name not in self.columns:
+            raise KeyError(f"news store has no categorical column {name!r} (has: {sorted(self.columns)})")
+        return self.columns[name]
 
     # ---- construction from the reference's in-memory dict (mind.py:161-164)
     @classmethod
-    def from_news_feat(cls, news_feat: dict, feature: str = "title_emb", catg_features: Sequence[str] = ()):
+    def from_news_feat(cls, news_feat: dict, feature: str = "title_emb", catg_features: Sequence[str] = (),
+                       text_features: Sequence[str] = ()):
+        """`text_features`: additional text features stored next to `feature` (e.g. ['abstract_emb'])."""
         ids = list(news_feat.keys())
-        first = news_feat[ids[0]][feature]
-        S, D = np.asarray(first[0]).shape[-2:]
-        x = np.zeros((len(ids) + 1, S, D), dtype=np.float32)
-        m = np.zeros((len(ids) + 1, S), dtype=np.float32)
-        for i, nid in enumerate(ids):
-            emb, mask = news_feat[nid][feature]
-            x[i + 1] = np.asarray(emb, dtype=np.float32).reshape(S, D)
-            m[i + 1] = np.asarray(mask, dtype=np.float32).reshape(S)
+
+        def table(feat):
+            first = news_feat[ids[0]][feat]
+            S, D = np.asarray(first[0]).shape[-2:]
+            x = np.zeros((len(ids) + 1, S, D), dtype=np.float32)
+            m = np.zeros((len(ids) + 1, S), dtype=np.float32)
+            for i, nid in enumerate(ids):
+                emb, mask = news_feat[nid][feat]
+                x[i + 1] = np.asarray(emb, dtype=np.float32).reshape(S, D)
+                m[i + 1] = np.asarray(mask, dtype=np.float32).reshape(S)
+            return torch.from_numpy(x), torch.from_numpy(m)
+
+        x, m = table(feature)
+        texts = {f: table(f) for f in text_features if f != feature}
         cols = {}
         for f in catg_features:
             c = np.zeros((len(ids) + 1,), dtype=np.int32)  # pad label 0 (stack_scalars, xnrs/utils.py:66-73)
             for i, nid in enumerate(ids):
                 c[i + 1] = int(news_feat[nid][f])
             cols[f] = torch.from_numpy(c)
-        return cls(torch.from_numpy(x), torch.from_numpy(m), ids, cols)
+        return cls(x, m, ids, cols, texts, feature)
 
     def to(self, device):
-        return NewsStore(self.x.to(device), self.m.to(device), self.ids, {k: v.to(device) for k, v in self.columns.items()})
+        return NewsStore(self.x.to(device), self.m.to(device), self.ids, {k: v.to(device) for k, v in self.columns.items()},
+                         {k: (tx.to(device), tm.to(device)) for k, (tx, tm) in self.texts.items()}, self.feature)
 
     def rows(self, news_ids: Sequence) -> List[int]:
         return [self.index[n] for n in news_ids]
 
-    def gather(self, rows: torch.Tensor):
+    def check_rows(self, rows: torch.Tensor, what: str = "rows") -> torch.Tensor:
+        """int32, contiguous, on the table's device, every id inside [0, n_rows) -- a kernel never sees an id it would
+        read out of bounds with (one host sync; callers on a hot loop validate their id arrays once and pass
+        trusted=True to gather)."""
+        if not rows.is_cuda or not self.x.is_cuda:
+            raise hip.XnrsHipError(f"NewsStore: the table and the {what} must live on the HIP device")
+        flat = rows.reshape(-1).to(torch.int32).contiguous()
+        if flat.numel():
+            lo, hi = int(flat.min().item()), int(flat.max().item())
+            if lo < 0 or hi >= self.n_rows:
+                raise IndexError(f"NewsStore: {what} out of range [{lo}, {hi}] for a table of {self.n_rows} rows")
+        return flat
+
+    def gather(self, rows: torch.Tensor, feature: Optional[str] = None, trusted: bool = False):
         """Dense (x:(*rows.shape,S,D), m:(*rows.shape,S,1)) for int32 table rows -- the tensors the reference's dataset
         would have built on the host (dataset.py:63-85,97-109).  Only for consumers that need the batch itself (input
         gradients of the explainer); the encoders take the rows directly (forward_ids)."""
-        if not self.x.is_cuda or not rows.is_cuda:
-            raise hip.XnrsHipError("NewsStore.gather: the table and the rows must live on the HIP device")
-        flat = rows.reshape(-1).to(torch.int32).contiguous()
-        n, (S, D) = flat.numel(), self.x.shape[1:]
-        x = torch.empty((n, S, D), dtype=torch.float32, device=self.x.device)
-        m = torch.empty((n, S), dtype=torch.float32, device=self.x.device)
-        st = hip.stream_ptr(self.x.device)
-        hip.check(hip.lib().xnrs_gather_rows(hip.ptr(self.x), hip.ptr(flat), hip.ptr(x), n, S * D, st), "xnrs_gather_rows(x)")
-        hip.check(hip.lib().xnrs_gather_rows(hip.ptr(self.m), hip.ptr(flat), hip.ptr(m), n, S, st), "xnrs_gather_rows(m)")
+        tx, tm = self.text(feature or self.feature)
+        tx, tm = hip.dev_f32(tx, "news table"), hip.dev_f32(tm, "news table mask")
+        flat = rows.reshape(-1).to(torch.int32).contiguous() if trusted else self.check_rows(rows)
+        if not flat.is_cuda:
+            raise hip.XnrsHipError("NewsStore.gather: the rows must live on the HIP device")
+        n, (S, D) = flat.numel(), tx.shape[1:]
+        x = torch.empty((n, S, D), dtype=torch.float32, device=tx.device)
+        m = torch.empty((n, S), dtype=torch.float32, device=tx.device)
+        st = hip.stream_ptr(tx.device)
+        hip.check(hip.lib().xnrs_gather_rows(hip.ptr(tx), hip.ptr(flat), hip.ptr(x), n, S * D, st), "xnrs_gather_rows(x)")
+        hip.check(hip.lib().xnrs_gather_rows(hip.ptr(tm), hip.ptr(flat), hip.ptr(m), n, S, st), "xnrs_gather_rows(m)")
         return x.reshape(*rows.shape, S, D), m.reshape(*rows.shape, S, 1)
 
-    # ---- flat on-disk format: <path>.json (header) + <path>.x.f32 + <path>.m.u8 (+ <path>.<col>.i32)
-    def save(self, path: str) -> None:
-        x = self.x.detach().cpu().numpy()
-        m = self.m.detach().cpu().numpy()
-        header = {"magic": MAGIC, "n_rows": int(x.shape[0]), "S": int(x.shape[1]), "D": int(x.shape[2]),
-                  "ids": [str(i) for i in self.ids], "columns": sorted(self.columns)}
+    def gather_column(self, name: str, rows: torch.Tensor) -> torch.Tensor:
+        """Categorical feature of the given table rows (index bookkeeping: an int32 look-up)."""
+        return self.column(name)[rows.long()]
+
+    # ---- flat on-disk format (replaces the pandas pickle of mind.py:161-164):
+    #   <path>.json                       header
+    #   <path>.x.f32  <path>.m.u8         primary text feature  [n_rows,S,D] fp32 / [n_rows,S] u8
+    #   <path>.<feat>.x.f32 / .m.u8       further text features
+    #   <path>.<col>.i32                  categorical columns
+    def _files(self, path: str):
+        yield self.feature, path + ".x.f32", path + ".m.u8"
+        for k in sorted(self.texts):
+            yield k, f"{path}.{k}.x.f32", f"{path}.{k}.m.u8"
+
+    def save(self, path: str, rows_per_chunk: int = 4096) -> None:
+        header = {"magic": MAGIC, "n_rows": int(self.n_rows), "S": int(self.x.shape[1]), "D": int(self.x.shape[2]),
+                  "ids": [str(i) for i in self.ids], "columns": sorted(self.columns), "feature": self.feature,
+                  "texts": {k: {"S": int(tx.shape[1]), "D": int(tx.shape[2])} for k, (tx, tm) in sorted(self.texts.items())}}
         with open(path + ".json", "w") as f:
             json.dump(header, f)
-        x.astype(np.float32).tofile(path + ".x.f32")
-        m.astype(np.uint8).tofile(path + ".m.u8")
+        for feat, fx, fm in self._files(path):
+            tx, tm = self.text(feat)
+            with open(fx, "wb") as f:  # chunked: a 10-GB table never needs a second whole copy on the host
+                for lo in range(0, self.n_rows, rows_per_chunk):
+                    f.write(tx[lo:lo + rows_per_chunk].detach().cpu().numpy().astype(np.float32, copy=False).tobytes())
+            tm.detach().cpu().numpy().astype(np.uint8).tofile(fm)
         for k, v in self.columns.items():
             v.detach().cpu().numpy().astype(np.int32).tofile(f"{path}.{k}.i32")
 
-    @classmethod
-    def load(cls, path: str, mmap: bool = True):
+    @staticmethod
+    def _open(path: str):
+        """Header + read-only memory maps of every payload file (nothing is read yet)."""
         with open(path + ".json") as f:
             h = json.load(f)
-        if h.get("magic") != MAGIC:
+        if h.get("magic") not in (MAGIC, _MAGIC_V1):
             raise ValueError(f"{path}.json is not a {MAGIC} header")
-        n, S, D = h["n_rows"], h["S"], h["D"]
-        if os.path.getsize(path + ".x.f32") != n * S * D * 4 or os.path.getsize(path + ".m.u8") != n * S:
-            raise ValueError("news store payload size does not match its header")
-        if mmap:
-            x = np.memmap(path + ".x.f32", dtype=np.float32, mode="r", shape=(n, S, D))
-            m = np.memmap(path + ".m.u8", dtype=np.uint8, mode="r", shape=(n, S))
-        else:
-            x = np.fromfile(path + ".x.f32", dtype=np.float32).reshape(n, S, D)
-            m = np.fromfile(path + ".m.u8", dtype=np.uint8).reshape(n, S)
-        cols = {k: torch.from_numpy(np.fromfile(f"{path}.{k}.i32", dtype=np.int32)) for k in h["columns"]}
-        # np.array(...) copies out of the read-only mapping page by page (no second whole-file buffer on top of
-        # the page cache); the caller then moves the tensors to the device once
-        return cls(torch.from_numpy(np.array(x)), torch.from_numpy(np.array(m)).float(), h["ids"], cols)
+        n = h["n_rows"]
+        feats = [(h.get("feature", "title_emb"), path + ".x.f32", path + ".m.u8", h["S"], h["D"])]
+        for k, sd in sorted(h.get("texts", {}).items()):
+            feats.append((k, f"{path}.{k}.x.f32", f"{path}.{k}.m.u8", sd["S"], sd["D"]))
+        maps = {}
+        for feat, fx, fm, S, D in feats:
+            if os.path.getsize(fx) != n * S * D * 4 or os.path.getsize(fm) != n * S:
+                raise ValueError(f"news store payload size does not match its header ({feat})")
+            maps[feat] = (np.memmap(fx, dtype=np.float32, mode="r", shape=(n, S, D)),
+                          np.memmap(fm, dtype=np.uint8, mode="r", shape=(n, S)))
+        cols = {}
+        for k in h["columns"]:
+            if os.path.getsize(f"{path}.{k}.i32") != n * 4:
+                raise ValueError(f"news store column {k} does not match its header")
+            cols[k] = torch.from_numpy(np.fromfile(f"{path}.{k}.i32", dtype=np.int32))
+        return h, feats, maps, cols
+
+    @classmethod
+    def load(cls, path: str, mmap: bool = True):
+        """Host copy of a saved store.  mmap=True: the tensors are VIEWS of read-only memory maps (pages are read on
+        first touch, no whole-table buffer is allocated); mmap=False reads the files into RAM.  To put a table into HBM
+        use load_to_device -- it never holds more than one chunk on the host."""
+        h, feats, maps, cols = cls._open(path)
+
+        def host(feat):
+            mx, mm = maps[feat]
+            if mmap:
+                import warnings
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")  # "non-writable array": the store is read-only by contract
+                    return torch.from_numpy(mx), torch.from_numpy(np.asarray(mm)).float()
+            return torch.from_numpy(np.array(mx)), torch.from_numpy(np.array(mm)).float()
+
+        primary = feats[0][0]
+        x, m = host(primary)
+        texts = {f[0]: host(f[0]) for f in feats[1:]}
+        return cls(x, m, h["ids"], cols, texts, primary)
+
+    @classmethod
+    def load_to_device(cls, path: str, device, rows_per_chunk: int = 2048, stats: Optional[dict] = None):
+        """File -> HBM without a whole-table host copy (replaces the pandas pickle load of
+        xnrs/data/mind.py:161-164): the device table is allocated once, the file is memory-mapped, and chunks of
+        `rows_per_chunk` rows travel through TWO reused pinned staging buffers (the copy of chunk i overlaps the page-in
+        of chunk i+1) straight into their rows of the table.  The u8 mask is widened to the fp32 0/1 mask the kernels
+        read after it has landed (one elementwise cast of S bytes per row: data movement, not hot-path arithmetic).
+        `stats` (optional dict) receives bytes / seconds / GB/s."""
+        import time
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise hip.XnrsHipError("NewsStore.load_to_device: the target must be a HIP device")
+        h, feats, maps, cols = cls._open(path)
+        n = h["n_rows"]
+        t0 = time.perf_counter()
+        nbytes = 0
+        copy_stream = torch.cuda.Stream(device=dev)
+        out = {}
+        for feat, fx, fm, S, D in feats:
+            mx, mm = maps[feat]
+            tx = torch.empty((n, S, D), dtype=torch.float32, device=dev)
+            rpc = max(1, min(int(rows_per_chunk), n))
+            pinned = [torch.empty((rpc, S, D), dtype=torch.float32).pin_memory() for _ in range(2)]
+            done = [torch.cuda.Event(), torch.cuda.Event()]
+            used = [False, False]
+            with torch.cuda.stream(copy_stream):
+                for i, lo in enumerate(range(0, n, rpc)):
+                    hi = min(lo + rpc, n)
+                    b = i & 1
+                    if used[b]:
+                        done[b].synchronize()  # the previous copy out of this staging buffer has landed
+                    np.copyto(pinned[b][:hi - lo].numpy(), mx[lo:hi])  # page-in: file -> pinned buffer
+                    tx[lo:hi].copy_(pinned[b][:hi - lo], non_blocking=True)
+                    done[b].record(copy_stream)
+                    used[b] = True
+                mu8 = torch.from_numpy(np.array(mm)).pin_memory()
+                tm = mu8.to(dev, non_blocking=True).to(torch.float32)
+            nbytes += mx.nbytes + mm.nbytes
+            out[feat] = (tx, tm)
+        copy_stream.synchronize()
+        torch.cuda.current_stream(dev).wait_stream(copy_stream)
+        dt = time.perf_counter() - t0
+        if stats is not None:
+            stats.update(bytes=int(nbytes), seconds=dt, gb_per_s=nbytes / dt / 1e9, rows=int(n), rows_per_chunk=int(rows_per_chunk))
+        primary = feats[0][0]
+        x, m = out.pop(primary)
+        return cls(x, m, h["ids"], {k: v.to(dev) for k, v in cols.items()}, out, primary)
 
 
 def _csr(lists: List[List[int]]):

@@ -15,13 +15,22 @@ METRIC_NAMES = ("ndcg@5", "ndcg@10", "rr", "ctr@1", "ctr@10", "auc", "acc", "rec
 
 
 @torch.no_grad()
-def encode_news_table(model, store: NewsStore, chunk: int = 0):
-    """All rows of the store through model.news_encoder -> (vecs:(n_rows,E), hm:(n_rows,1)).  Row 0 (the
-    empty slot) gets the encoder's output for an all-padded news (head-bias leak, SURVEY.md finding 4)."""
-    n = store.x.shape[0]
-    ids = torch.arange(n, dtype=torch.int32, device=store.x.device).reshape(1, n)
-    y, hm = model.news_encoder.forward_ids(store.x, store.m, ids)
-    return y[0], hm[0]
+def encode_news_table(model, store: NewsStore, rows_per_call: int = 0):
+    """All rows of the store through the model's news tower -> (vecs:(n_rows,E), hm:(n_rows,1)).  Row 0 (the
+    empty slot) gets the tower's output for an all-padded news (head-bias leak, SURVEY.md finding 4).
+
+    Works for every model on the path through its `encode_news_ids(store, ids)` hook (ParentRec: one TextEncoder over
+    the title table; NAML: title + abstract tables and the two category columns, naml.py:76-107).  `rows_per_call`
+    bounds the rows handed to one hook call (0 = all at once; the C ABI chunks its own workspace either way)."""
+    n = store.n_rows
+    step = n if rows_per_call <= 0 else int(rows_per_call)
+    ys, hms = [], []
+    for lo in range(0, n, step):
+        ids = torch.arange(lo, min(lo + step, n), dtype=torch.int32, device=store.x.device).reshape(1, -1)
+        y, hm = model.encode_news_ids(store, ids)
+        ys.append(y[0])
+        hms.append(hm[0])
+    return (ys[0], hms[0]) if len(ys) == 1 else (torch.cat(ys), torch.cat(hms))
 
 
 def score_csr(vecs: torch.Tensor, cand_rows: torch.Tensor, cand_sess: torch.Tensor, u: torch.Tensor, relu: bool = True):
@@ -55,7 +64,7 @@ def evaluate(model, store: NewsStore, behaviors: Behaviors, l_hist: int, batch: 
         hist, off, rows, csess, targets = batcher.eval_batch(sess)
         h = vecs[hist.long()]            # (B, l_hist, E) row gather of pre-encoded vectors (data movement only)
         m = hm[hist.long()]
-        u = model.user_encoder((h, m), None)
+        u = model.encode_user(h, m)
         r = score_csr(vecs, rows, csess, u, relu=True)
         sums += rank_metrics(r, targets, off).double().sum(0)
     return {k: float(v) / n for k, v in zip(METRIC_NAMES, sums.tolist())}

@@ -96,16 +96,19 @@ class NAML(nn.Module):
         self.rec_model = rec_model
         self.emb_dim = cfg.total_emb_dim
 
+    def _pool_views(self, t, a, cat, sub):
+        """naml.py:94-107: concat the four views per news, additive attention over them (no mask)."""
+        b, n, _ = t.shape
+        stacked = torch.cat([t, a, cat, sub], dim=2).reshape(b * n, 4, self.emb_dim)
+        return self.feature_pooler(stacked).reshape(b, n, self.emb_dim)
+
     def _news_vectors(self, feats: dict):
         """One side (history or candidates), naml.py:76-107 -> ((B,N,E), title mask (B,N,1))."""
         dev = self.cat_fc.weight.device
         t, tm = self.title_encoder(feats['title_emb'])
         a, _ = self.body_encoder(feats['abstract_emb'])
-        views = [t, a, ops.embedding_linear(feats['category_index'].to(dev), self.cat_embedder, self.cat_fc),
-                 ops.embedding_linear(feats['subcategory_index'].to(dev), self.subcat_embedder, self.subcat_fc)]
-        b, n, _ = t.shape
-        stacked = torch.cat(views, dim=2).reshape(b * n, len(views), self.emb_dim)
-        return self.feature_pooler(stacked).reshape(b, n, self.emb_dim), tm
+        return self._pool_views(t, a, ops.embedding_linear(feats['category_index'].to(dev), self.cat_embedder, self.cat_fc),
+                                ops.embedding_linear(feats['subcategory_index'].to(dev), self.subcat_embedder, self.subcat_fc)), tm
 
     def get_user_embeddings(self, batch: dict):
         """naml.py:113-147 -> (B,1,E), not squeezed (like the reference)."""
@@ -114,6 +117,53 @@ class NAML(nn.Module):
     def forward(self, batch: dict):
         cand, _ = self._news_vectors(batch['candidate_features'])
         return self.rec_model(self.get_user_embeddings(batch), cand)
+
+    # ---- device-resident data path: the same hooks as ParentRec (blocks.py).  A NAML news needs FOUR things by its row
+    # id -- title tokens, abstract tokens, category, sub-category (dataset.py:63-124 gathers all of them by the same news
+    # id) -- so the store carries two token tables and two int32 columns; both TextEncoders gather their rows inside
+    # their first GEMM's load and the two embedding->Linear views are one row-gathered GEMM each.
+    title_feature, body_feature = 'title_emb', 'abstract_emb'
+    cat_column, subcat_column = 'category_index', 'subcategory_index'
+
+    def encode_news_ids(self, store, ids: torch.Tensor, dedup: bool = False):
+        """News vectors of table rows `ids:(B,N)` -> (vecs:(B,N,E), title mask:(B,N,1)).  dedup=True encodes every
+        distinct row once and scatters the vectors back (less algorithmic work: reported separately)."""
+        b, n = ids.shape
+        flat = ids.reshape(1, -1)
+        inv = None
+        if dedup:
+            uniq, inv = torch.unique(flat.reshape(-1), return_inverse=True)  # index bookkeeping only
+            flat = uniq.reshape(1, -1)
+        t, tm = self.title_encoder.forward_ids(*store.text(self.title_feature), flat)
+        a, _ = self.body_encoder.forward_ids(*store.text(self.body_feature), flat)
+        rows = flat.long()
+        cat = ops.embedding_linear(store.column(self.cat_column)[rows], self.cat_embedder, self.cat_fc)
+        sub = ops.embedding_linear(store.column(self.subcat_column)[rows], self.subcat_embedder, self.subcat_fc)
+        v = self._pool_views(t, a, cat, sub)[0]
+        tm = tm[0]
+        if inv is not None:
+            v, tm = v[inv], tm[inv]
+        return v.reshape(b, n, self.emb_dim), tm.reshape(b, n, 1)
+
+    def encode_user(self, h: torch.Tensor, hm: torch.Tensor) -> torch.Tensor:
+        return self.user_encoder(h, hm)
+
+    def forward_store(self, store, hist_ids: torch.Tensor, cand_ids: torch.Tensor, return_embeddings: bool = False,
+                      dedup: bool = False):
+        """forward() with the batch given as table rows of a NewsStore (row 0 = the empty history slot: all-zero tokens
+        and masks, category 0 -- exactly the padding of dataset.py:82-85 and stack_scalars)."""
+        H = hist_ids.shape[1]
+        if dedup:
+            v, vm = self.encode_news_ids(store, torch.cat([hist_ids, cand_ids], dim=1), dedup=True)
+            h, hm, c = v[:, :H].contiguous(), vm[:, :H].contiguous(), v[:, H:].contiguous()
+        else:
+            h, hm = self.encode_news_ids(store, hist_ids)
+            c, _ = self.encode_news_ids(store, cand_ids)
+        u = self.encode_user(h, hm)
+        r = self.rec_model(u, c)
+        return (r, u, c) if return_embeddings else r
+
+    forward_ids = forward_store
 
 
 class LSTURNewsEncoder(nn.Module):
@@ -130,13 +180,24 @@ class LSTURNewsEncoder(nn.Module):
         if 'subcategory_index' in cfg.catg_features:
             self.subcat_embedder = nn.Embedding(num_embeddings=cfg.n_subcategories + 1, embedding_dim=cfg.cat_emb_dim)
 
-    def forward(self, title_features, cat_idxs: torch.Tensor, subcat_idxs: Optional[torch.Tensor]):
-        emb, m = self.title_encoder(title_features)
+    def _concat(self, emb, cat_idxs, subcat_idxs):
         parts = [emb, self.cat_embedder(cat_idxs.to(emb.device).long())]  # table look-ups + concat: data movement only
         if subcat_idxs is not None:
             assert hasattr(self, 'subcat_embedder')
             parts.append(self.subcat_embedder(subcat_idxs.to(emb.device).long()))
-        return torch.cat(parts, dim=2), m
+        return torch.cat(parts, dim=2)
+
+    def forward(self, title_features, cat_idxs: torch.Tensor, subcat_idxs: Optional[torch.Tensor]):
+        emb, m = self.title_encoder(title_features)
+        return self._concat(emb, cat_idxs, subcat_idxs), m
+
+    def forward_ids(self, store, ids: torch.Tensor, dedup: bool = False):
+        """forward() by table rows `ids:(B,N)` of a NewsStore: tokens gathered in the first GEMM's load, the category
+        columns looked up by the same rows (dataset.py:111-124)."""
+        emb, m = self.title_encoder.forward_ids(*store.text('title_emb'), ids, dedup=dedup)
+        rows = ids.long()
+        sub = store.column('subcategory_index')[rows] if hasattr(self, 'subcat_embedder') else None
+        return self._concat(emb, store.column('category_index')[rows], sub), m
 
 
 # ------------------------------------------------------------------------------------------- factory

@@ -224,3 +224,20 @@ class ParentRec(nn.Module):
             h, hm = self.news_encoder.forward_ids(table_x, table_m, hist_ids)
             c, _ = self.news_encoder.forward_ids(table_x, table_m, cand_ids)
         return self._score(h.contiguous(), hm.contiguous(), c.contiguous(), None, return_embeddings)
+
+    # ---- the per-model hooks of the device-resident data path (xnrs_amd.data / xnrs_amd.evaluation): every model on
+    # the path answers the same three questions, whatever its news tower consumes
+    def encode_news_ids(self, store, ids: torch.Tensor, dedup: bool = False):
+        """News vectors of table rows `ids:(B,N)` of a NewsStore -> (vecs:(B,N,E), news mask:(B,N,1))."""
+        tx, tm = store.text(self.text_feature)
+        return self.news_encoder.forward_ids(tx, tm, ids, dedup=dedup)
+
+    def encode_user(self, h: torch.Tensor, hm: torch.Tensor) -> torch.Tensor:
+        """(B,H,E) history vectors + (B,H,1) mask -> (B,1,E) user vector."""
+        return self.user_encoder((h, hm), None)
+
+    def forward_store(self, store, hist_ids: torch.Tensor, cand_ids: torch.Tensor, return_embeddings: bool = False,
+                      dedup: bool = False):
+        """forward() with the batch given as table rows of a NewsStore (what DeviceBatcher hands out)."""
+        tx, tm = store.text(self.text_feature)
+        return self.forward_ids(tx, tm, hist_ids, cand_ids, return_embeddings=return_embeddings, dedup=dedup)
