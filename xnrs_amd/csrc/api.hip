@@ -300,6 +300,31 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
     fc1_w = wf;
   }
 
+  // Additive-only towers (no self-attention: StandardRec / BaseRec / NAML / LSTUR news encoders) from a batch that fills
+  // the chip: fc1 + tanh + fc2 + exp + mask + normalise + weighted sum as ONE persistent launch (additive_fused.hip).  Its
+  // result equals the GEMM + pooling pipeline's bit for bit (same MFMA fragments and k order, same reduction orders), so
+  // the choice may depend on the batch size without a news vector ever changing: below one 256-row tile per CU the
+  // pipeline's smaller tiles fill the chip better.
+  bool afused = !att && additive && !train && !a_out && gemm_mode() == 0 && knobs().additive_fused &&
+                additive_fused_plan(L, D, A, nullptr, nullptr) && rowdot &&
+                (knobs().additive_fused == 2 || additive_fused_tiles(n_seq, L) >= 256);
+  if (afused) {
+    AdditiveFusedArgs af{};
+    af.x = x; af.ids = ids; af.mask = m;
+    af.w1 = pool->w1; af.b1 = pool->b1; af.w2 = pool->w2; af.b2 = pool->b2;
+    af.y = head ? pb : y;
+    af.ldy = D;
+    af.hm = m ? hm : nullptr;
+    af.n_seq = n_seq;
+    af.S = L; af.D = D; af.A = A;
+    afused = additive_fused_ready(af);
+    if (afused) {
+      const double fl = (double)n_seq * (2.0 * L * D * A + 2.0 * L * (A + D));
+      ProfScope ps(3, fl, stream);
+      XNRS_TRY(launch_additive_fused(af, stream));
+    }
+  }
+
   // bf16-split GEMM modes: split the weights ONCE per call (the chunk loop below reuses them ~20 times per step)
   const unsigned short *pq = nullptr, *pk = nullptr, *pv = nullptr, *po = nullptr, *p1 = nullptr;
   if (gemm_mode() != 0) {
@@ -333,7 +358,7 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
     ProfScope ps(6, fl, stream);
     XNRS_TRY(launch_news_fused(f, stream));
   }
-  for (int64_t c0 = 0; !fused && c0 < n_seq; c0 += p.chunk) {
+  for (int64_t c0 = 0; !fused && !afused && c0 < n_seq; c0 += p.chunk) {
     const int64_t nc = (n_seq - c0 < p.chunk) ? (n_seq - c0) : p.chunk;
     const int64_t rows = nc * L;
     // this chunk's view of the inputs

@@ -546,10 +546,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          float v = acc[i][j][e] + bv;
-          if (a.act == 1) v = fmaxf(v, 0.f);
-          else if (a.act == 2) v = tanhf(v);
-          v *= wv;
+          float v = apply_act(acc[i][j][e] + bv, a.act) * wv;
 #pragma unroll
           for (int off = 1; off < 32; off <<= 1) v += __shfl_xor(v, off);
           const int64_t row = m0 + wm * 32 * TM + 32 * i + (e & 3) + 8 * (e >> 2) + crow;
@@ -577,9 +574,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
           }
           float v = acc[i][j][e];
           if (!split) {
-            v += bv;
-            if (a.act == 1) v = fmaxf(v, 0.f);
-            else if (a.act == 2) v = tanhf(v);
+            v = apply_act(v + bv, a.act);
             if (a.aux_mode) {
               const float x = a.aux[row * a.ldaux + coff];
               v *= (a.aux_mode == 1) ? (1.f - x * x) : (x > 0.f ? 1.f : 0.f);
@@ -804,6 +799,9 @@ static Knobs read_knobs() {
   k.fold_train = (int)num("XNRS_FOLD_TRAIN", 1);
   k.news_fused = (int)num("XNRS_NEWS_FUSED", 1);
   k.news_fused_npw = (int)num("XNRS_NEWS_FUSED_NPW", 0);
+  k.fast_tanh = num("XNRS_FAST_TANH", 1) != 0;
+  k.additive_fused = (int)num("XNRS_ADDITIVE_FUSED", 1);
+  k.af_fbuf = num("XNRS_AF_FBUF", 1) == 2 ? 2 : 1;
   const long long m = num("XNRS_GEMM_MODE", 0);
   k.gemm_mode_init = (m >= 0 && m <= 2) ? (int)m : 0;
   return k;
@@ -818,6 +816,7 @@ void set_gemm_mode(int mode) { g_gemm_mode.store((mode >= 0 && mode <= 2) ? mode
 hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t stream, int* nsplit_used) {
   GemmArgs a = a_in;
   if (a.M <= 0 || a.Nseg <= 0) return hipSuccess;
+  if (a.act == 2 && knobs().fast_tanh) a.act = ACT_TANH_FAST;
   if (a.K >= (1ll << 31)) return hipErrorInvalidValue;  // 32-bit contraction indices in the kernel
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   // 16-byte vector loads need the contiguous dimension of each operand on 16-B boundaries

@@ -287,9 +287,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_split_kernel(GemmArgs a, int m
             const int64_t n = row / a.gather_S;
             row = (int64_t)(a.c_scatter_ids ? a.c_scatter_ids : a.gather_ids)[n] * a.gather_S + (row - n * a.gather_S);
           }
-          float v = acc[i][j][e] + bv;
-          if (a.act == 1) v = fmaxf(v, 0.f);
-          else if (a.act == 2) v = tanhf(v);
+          float v = apply_act(acc[i][j][e] + bv, a.act);
           if (a.aux_mode) {
             const float x = a.aux[row * a.ldaux + coff];
             v *= (a.aux_mode == 1) ? (1.f - x * x) : (x > 0.f ? 1.f : 0.f);

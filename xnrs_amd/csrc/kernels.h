@@ -33,6 +33,10 @@ struct Knobs {
                                 // (news_fused.hip); 1 = where it is faster (S >= 26, >= 192 news)
   int news_fused_npw = 0;       // XNRS_NEWS_FUSED_NPW=1|2 force the news per workgroup of the fused encoder; 0 = by batch size
   int gemm_mode_init = 0;       // XNRS_GEMM_MODE=0|1|2: initial forward-GEMM arithmetic (see gemm_mode())
+  bool fast_tanh = true;        // XNRS_FAST_TANH=0: ocml tanhf in the tanh epilogues instead of xnrs::fast_tanh
+  int additive_fused = 1;       // XNRS_ADDITIVE_FUSED=0|2: never / whenever eligible use the one-launch additive encoder
+                                // (additive_fused.hip); 1 = from a batch that fills the chip (results are bitwise equal)
+  int af_fbuf = 1;              // XNRS_AF_FBUF=1|2: MFMA fragment register sets of that kernel
 };
 const Knobs& knobs();
 void reload_knobs();
@@ -193,6 +197,28 @@ __device__ __forceinline__ int64_t xcd_pair(int64_t L, int64_t W, int n_heads) {
 
 __device__ __forceinline__ float attn_exp(float x) { return __expf(x); }
 
+// tanh for the activation epilogues (the additive pooler's tanh(fc1 x), layers.py:60; a Tanh head): the hardware exp2 and
+// reciprocal instead of ocml's tanhf (~12 instead of ~60 VALU instructions per element with both branches of the ocml
+// version executed; the fc1 epilogue was 15 % of that GEMM).  |x| >= 1/8: 1 - 2 / (exp(2x) + 1), absolute error <= ~1.5e-7
+// (relative <= ~1.2e-6); |x| < 1/8: the odd Taylor polynomial to x^7 (relative error < 3e-9 + rounding), so small
+// arguments keep their relative accuracy.  Saturates to +-1, propagates NaN.  Parity bar 1e-4; XNRS_FAST_TANH=0 = tanhf.
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);  // exp(2x)
+  const float big = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+  const float x2 = x * x;
+  const float small = x * fmaf(x2, fmaf(x2, fmaf(x2, -17.f / 315.f, 2.f / 15.f), -1.f / 3.f), 1.f);
+  return fabsf(x) < 0.125f ? small : big;
+}
+// activation codes inside the kernels: XNRS_ACT_* (0 none, 1 relu, 2 tanh) plus 3 = tanh through fast_tanh; the launchers
+// turn 2 into 3 when the knob is on
+constexpr int ACT_TANH_FAST = 3;
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == 1) return fmaxf(v, 0.f);
+  if (act == 3) return fast_tanh(v);
+  if (act == 2) return tanhf(v);
+  return v;
+}
+
 // counter-based RNG for attention dropout (training mode only): splitmix64 finaliser on
 // (seed, element index) -> uniform [0,1).  Parity with torch's CPU Philox stream is impossible
 // (SURVEY.md section 7 "hard parts"); only the distribution matters.  Forward and backward call this with
@@ -220,6 +246,7 @@ struct NewsFusedArgs {
   int64_t n_seq;
   int32_t S, D, n_heads, d_k, A, scaled;
   int32_t npw;         // news per workgroup: 2 (default, 0 means 2) or 1
+  int32_t tanh_act;    // filled in by the launcher: 2 = ocml tanhf, 3 = fast_tanh (knob)
 };
 struct NewsFusedPlan {
   int npw, hg, lq, ly;  // news per workgroup, heads per group, LDS row strides of the Q|K|V and Y images
@@ -234,6 +261,26 @@ size_t news_fused_img_bound_bytes(int S, int D, int A);  // >= img_bytes for eve
 // false = use the GEMM pipeline for this call
 bool news_fused_ready(const NewsFusedArgs& a);
 hipError_t launch_news_fused(const NewsFusedArgs& a, hipStream_t stream);
+
+// ---------------------------------------------------------------- additive encoder in one launch (additive_fused.hip)
+// fc1 + tanh + fc2 + exp * mask + normalise + weighted sum of a TextEncoder WITHOUT self-attention (layers.py:60-65):
+// persistent workgroups over tiles of whole news; bit-identical to the GEMM + additive_pool pipeline
+struct AdditiveFusedArgs {
+  const float* x;      // [n_seq, S, D] token rows, or the table when ids != null
+  const int32_t* ids;  // nullable: news n is table row ids[n] (x and mask are then the table's)
+  const float* mask;   // [n_seq, S] fp32 0/1 (or table mask), nullable
+  const float *w1, *b1, *w2, *b2;  // fc1 [A][D], b1 [A] nullable, fc2 [A], b2 [1] nullable
+  float* y;            // [n_seq, ldy] pooled vectors
+  int64_t ldy;
+  float* hm;           // nullable [n_seq]: clamp(sum mask, 0, 1)
+  int64_t n_seq;
+  int32_t S, D, A;
+  int32_t tanh_act;    // filled in by the launcher
+};
+bool additive_fused_plan(int S, int D, int A, int* nn_out, int* pp_out);  // does the kernel cover the shape?
+bool additive_fused_ready(const AdditiveFusedArgs& a);                     // ... and these operands (alignment)?
+int64_t additive_fused_tiles(int64_t n_seq, int S);                        // 256-row tiles of whole news
+hipError_t launch_additive_fused(const AdditiveFusedArgs& a, hipStream_t stream);
 
 // ---------------------------------------------------------------- pooling / scoring
 struct AdditivePoolArgs {

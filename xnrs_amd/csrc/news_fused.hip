@@ -551,7 +551,7 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int rt = 0; rt < TR; ++rt) e[rt] = fmaf(w2[r], tanhf(acc[t][rt][r] + b1[r]), e[rt]);
+        for (int rt = 0; rt < TR; ++rt) e[rt] = fmaf(w2[r], apply_act(acc[t][rt][r] + b1[r], a.tanh_act), e[rt]);
     }
 #pragma unroll
     for (int rt = 0; rt < TR; ++rt) {
@@ -706,7 +706,9 @@ bool news_fused_ready(const NewsFusedArgs& a) {
   return nf_attr_ok(a.d_k / 4, npw, dev);
 }
 
-hipError_t launch_news_fused(const NewsFusedArgs& a, hipStream_t stream) {
+hipError_t launch_news_fused(const NewsFusedArgs& a_in, hipStream_t stream) {
+  NewsFusedArgs a = a_in;
+  a.tanh_act = knobs().fast_tanh ? ACT_TANH_FAST : 2;
   if (a.n_seq <= 0) return hipSuccess;
   NewsFusedPlan p;
   const int npw = a.npw == 1 ? 1 : 2;
