@@ -101,11 +101,11 @@ def test_fused_reproduces_the_reference_goldens(name):
 
 
 def test_default_dispatch_takes_the_fused_kernel_from_a_full_chip_on():
-    """Default knob: >= 256 tiles (one per CU) -> the fused launch (profile stage 3 records ONE launch and no pooling
+    """Default knob: >= 768 tiles (three per CU) -> the fused launch (profile stage 3 records ONE launch and no pooling
     launch), fewer -> the pipeline; the results agree bit for bit either way."""
     S, D, A = 50, 768, 256
     enc, _ = encoder(D, A, 256, True, False, 5)
-    for n, fused in ((1279, False), (1280, True)):
+    for n, fused in ((3835, False), (3836, True)):  # 767 and 768 tiles of 5 news
         x, m = tokens(n, S, D, 6, full_pad_prob=0.0)
         hip.profile_enable(0x3F)
         with torch.no_grad():

@@ -45,6 +45,11 @@ constexpr int AF_BM = 256, AF_BN = 256, AF_BK = 16;
 #define AF_WAVES 8
 #endif
 constexpr int AF_T = 64 * AF_WAVES;
+// diagnostic builds only (make afexp; tools/bench_af.py): bit 0 no pooling ticks, bit 1 no score epilogue, bit 2 no
+// barrier in the K loop, bit 3 no tile staging in the K loop, bit 4 no fragment reads -- wrong results, timing only; never shipped
+#ifndef AF_EXP
+#define AF_EXP 0
+#endif
 constexpr int AF_TM = AF_WAVES == 16 ? 2 : 4, AF_TN = 2;
 constexpr int AF_RPP = AF_T / 4;             // tile rows staged per pass (4 chunks of 16 bytes per row)
 constexpr int AF_NR = AF_BM / AF_RPP;        // rows per thread per operand tile
@@ -66,6 +71,7 @@ __global__ __launch_bounds__(AF_T, AF_WAVES / 4) void additive_fused_kernel(Addi
   __shared__ float s_ep[AF_BM * AF_EPS];
   __shared__ float s_w[AF_BM];
   __shared__ float s_wn[2][AF_BM];
+  __shared__ float2 s_bw[AF_BN];  // {b1[h], w2[h]} of every hidden unit, zeros past A
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;  // AF_WAVES / 4 x 4 waves
@@ -78,6 +84,9 @@ __global__ __launch_bounds__(AF_T, AF_WAVES / 4) void additive_fused_kernel(Addi
   const int npairs = nn * D4;
   const int n_ep = (A + 31) >> 5;
   const float b2 = a.b2 ? a.b2[0] : 0.f;
+
+  if (tid < AF_BN) s_bw[tid] = make_float2((a.b1 && tid < A) ? a.b1[tid] : 0.f, tid < A ? a.w2[tid] : 0.f);
+  // (published by the first K loop's barriers long before the first epilogue reads it)
 
   // ---- B operand (W1 [A][D], L2-resident): raw buffer loads, rows >= A and the k tail read zeros via the bounds check
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w1), 0, (int)((int64_t)A * D * 4), 0x00020000);
@@ -99,6 +108,14 @@ __global__ __launch_bounds__(AF_T, AF_WAVES / 4) void additive_fused_kernel(Addi
   f32x4 pacc[PP];
   f32x4 px[PP][AF_SPI];
   int p_issued = 0, p_cons = 0;
+#pragma unroll
+  for (int p = 0; p < PP; ++p) {  // before the first tile: any valid row (the sums are discarded)
+    pb[p] = a.x;
+    pwo[p] = 0;
+    pacc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < AF_SPI; ++s) px[p][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   auto pool_setup = [&](int64_t news0) {
 #pragma unroll
@@ -116,32 +133,35 @@ __global__ __launch_bounds__(AF_T, AF_WAVES / 4) void additive_fused_kernel(Addi
     p_issued = 0;
     p_cons = 0;
   };
-  // one tick: fold in the rows loaded by the previous tick (in row order), then load the next AF_SPI rows
-  auto pool_tick = [&]() {
-    if (p_cons < p_issued) {
+  // One tick per K iteration, BRANCH-FREE: fold in the AF_SPI rows loaded by the previous tick (in row order), then load
+  // the next AF_SPI.  Steps past S keep loading row S-1 (an L1 hit) and fold it in with weight 0 (x + 0 * finite = x; a
+  // non-finite token poisons the pipeline's sum just the same), and the first tile of a workgroup -- nothing to pool yet --
+  // runs the same instructions on its own first row and throws the sums away.  With conditional loads the compiler had
+  // to assume at every LDS store of the K loop that the pooling loads might NOT have been issued (s_waitcnt vmcnt(3)
+  // instead of 7), i.e. it drained them a few hundred cycles after their issue: 0.65 of the matrix peak.
+  auto pool_consume = [&]() {
 #pragma unroll
-      for (int s = 0; s < AF_SPI; ++s) {
-        const int st = p_cons + s;
-        if (st < S) {  // wave-uniform
+    for (int s = 0; s < AF_SPI; ++s) {
+      const int st = p_cons + s;
+      const int stc = st < S ? st : S - 1;
 #pragma unroll
-          for (int p = 0; p < PP; ++p) {
-            const float w = s_wn[prev_buf][pwo[p] + st];
+      for (int p = 0; p < PP; ++p) {
+        float w = s_wn[prev_buf][pwo[p] + stc];
+        w = st < S ? w : 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pacc[p][r] = fmaf(w, px[p][s][r], pacc[p][r]);
-          }
-        }
+        for (int r = 0; r < 4; ++r) pacc[p][r] = fmaf(w, px[p][s][r], pacc[p][r]);
       }
-      p_cons = p_issued;
     }
-    if (p_issued < S) {
+    p_cons += AF_SPI;
+  };
+  auto pool_issue = [&]() {
 #pragma unroll
-      for (int s = 0; s < AF_SPI; ++s) {
-        const int st = (p_issued + s < S) ? p_issued + s : S - 1;
+    for (int s = 0; s < AF_SPI; ++s) {
+      const int st = (p_issued + s < S) ? p_issued + s : S - 1;
 #pragma unroll
-        for (int p = 0; p < PP; ++p) px[p][s] = *reinterpret_cast<const f32x4*>(pb[p] + (int64_t)st * D);
-      }
-      p_issued += AF_SPI;
+      for (int p = 0; p < PP; ++p) px[p][s] = *reinterpret_cast<const f32x4*>(pb[p] + (int64_t)st * D);
     }
+    p_issued += AF_SPI;
   };
   auto pool_store = [&](int64_t news0) {
 #pragma unroll
@@ -223,11 +243,16 @@ __global__ __launch_bounds__(AF_T, AF_WAVES / 4) void additive_fused_kernel(Addi
     for (int w = 0; w < AF_NCH; ++w) sstore(0, w);
 #pragma unroll
     for (int w = 0; w < AF_NCH; ++w) gload(AF_BK * (1 < last ? 1 : last), w);
+    // the previous tile's rows 0 .. AF_SPI-1; every tick of the K loop folds in what the tick before loaded, then loads.
+    // Issued HERE, behind the tile loads, so that the loop is entered with the loads outstanding in the same order as
+    // around its back edge (tile loads, then pooling loads): the compiler's s_waitcnt vmcnt(N) in front of the LDS stores
+    // is the minimum over both ways in, and a pooling load issued before the prologue made it drain them every iteration
+    pool_issue();
     __syncthreads();
     for (int t = 0; t < nk; ++t) {
       const int buf = t & 1;
       const int kn = AF_BK * (t + 2 < last ? t + 2 : last);
-      ldfrag(0, buf, 0);
+      if (!(AF_EXP & 16) || t == 0) ldfrag(0, buf, 0);
 #pragma unroll
       for (int kq = 0; kq < 2; ++kq) {
 #pragma unroll
@@ -237,48 +262,54 @@ __global__ __launch_bounds__(AF_T, AF_WAVES / 4) void additive_fused_kernel(Addi
           for (int i = 0; i < AF_TM; ++i)
 #pragma unroll
             for (int j = 0; j < AF_TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kq % AF_FBUF][i][e], fb[kq % AF_FBUF][j][e], acc[i][j], 0, 0, 0);
-          if (AF_FBUF == 2 ? slot == 1 : slot == 3) ldfrag(1 % AF_FBUF, buf, 1);  // one register set: behind the group's last MFMAs
-          if (slot >= 1 && slot <= AF_NCH) sstore(buf ^ 1, slot - 1);      // tile t+1 -> LDS (a redundant re-store at the tail)
-          if (slot >= 2 && slot <= AF_NCH + 1) gload(kn, slot - 2);        // tile t+2 -> the register just stored
-          if (slot == 6 && have_prev) pool_tick();
+              // W1 . X^T: transposed blocks (tokens on the lanes, hidden units down the accumulator), see rowdot_block_t
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[kq % AF_FBUF][j][e], fa[kq % AF_FBUF][i][e], acc[i][j], 0, 0, 0);
+          if ((AF_FBUF == 2 ? slot == 1 : slot == 3) && !(AF_EXP & 16)) ldfrag(1 % AF_FBUF, buf, 1);  // one register set: behind the group's last MFMAs
+          if (!(AF_EXP & 8)) {
+            if (slot >= 1 && slot <= AF_NCH) sstore(buf ^ 1, slot - 1);      // tile t+1 -> LDS (a redundant re-store at the tail)
+            if (slot >= 2 && slot <= AF_NCH + 1) gload(kn, slot - 2);        // tile t+2 -> the register just stored
+          }
+          if (slot == 6 && !(AF_EXP & 1)) {
+            pool_consume();
+            pool_issue();
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      __syncthreads();
+      if (!(AF_EXP & 4)) __syncthreads();
     }
     if (have_prev) {  // rows the K loop had no iterations for (S > 2 (nk - 1): short contractions), then the result
-      while (p_cons < S) pool_tick();
+      while (p_cons < S) {
+        pool_consume();
+        pool_issue();
+      }
       pool_store(prev_news0);
     }
 
-    // ---- scores: v = tanh(acc + b1) w2, summed over the 32 columns of each MFMA block (butterfly inside the 32-lane
-    // half, the RDOT epilogue's order); lanes 0 / 32 park the block sum of their rows
-    const int ccol = lane & 31;
-    const int crow = 4 * (lane >> 5);
-    auto scores = [&](auto FAST) {  // the activation is chosen ONCE (a per-element switch kept all three versions inline)
+    // ---- scores: per transposed block an in-lane fmaf chain over 16 hidden units + one exchange with lane l ^ 32
+    // (rowdot_block_t, shared with the GEMM's RDOT epilogue); lanes 0..31 park the block sum of their token row
+    const int half = lane >> 5;
+    auto scores = [&](auto FAST) {
 #pragma unroll
       for (int j = 0; j < AF_TN; ++j) {
-        const int col = wn * 32 * AF_TN + 32 * j + ccol;
-        const bool cok = col < A;
-        const float bv = (a.b1 && cok) ? a.b1[col] : 0.f;
-        const float wv = cok ? a.w2[col] : 0.f;
         const int slot = wn * AF_TN + j;
 #pragma unroll
         for (int i = 0; i < AF_TM; ++i) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const float pre = acc[i][j][e] + bv;
-            float v = (decltype(FAST)::value ? fast_tanh(pre) : tanhf(pre)) * wv;
-#pragma unroll
-            for (int off = 1; off < 32; off <<= 1) v += __shfl_xor(v, off);
-            const int row = wm * 32 * AF_TM + 32 * i + (e & 3) + 8 * (e >> 2) + crow;
-            if (ccol == 0) s_ep[row * AF_EPS + slot] = v;
-          }
+          const float sc = rowdot_block_t<decltype(FAST)::value>(acc[i][j], s_bw + 32 * slot, half);
+          if (lane < 32) s_ep[(wm * 32 * AF_TM + 32 * i + lane) * AF_EPS + slot] = sc;
         }
       }
     };
-    if (a.tanh_act == ACT_TANH_FAST) scores(std::true_type{});
+    if (AF_EXP & 2) {  // every accumulator element used (no dead MFMAs), none of the score arithmetic
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < AF_TM; ++i)
+#pragma unroll
+        for (int j = 0; j < AF_TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) t += acc[i][j][e];
+      if (lane < 32) s_ep[(wm * 32 * AF_TM + lane) * AF_EPS + wn] = t;
+    } else if (a.tanh_act == ACT_TANH_FAST) scores(std::true_type{});
     else scores(std::false_type{});
     __syncthreads();
     // exp(score) * mask per tile row (the pooling kernel's thread-per-row arithmetic)
@@ -323,6 +354,8 @@ __global__ __launch_bounds__(AF_T, AF_WAVES / 4) void additive_fused_kernel(Addi
   // ---- the last tile of this workgroup: pooled on its own (8 rows in flight per pair)
   if (have_prev) {
     __syncthreads();
+#pragma unroll
+    for (int p = 0; p < PP; ++p) pacc[p] = f32x4{0.f, 0.f, 0.f, 0.f};  // from row 0 again (the pre-issued rows are dropped)
     constexpr int TB = PP <= 2 ? 8 : 4;  // rows in flight per pair
     for (int st0 = 0; st0 < S; st0 += TB) {
       f32x4 v[PP][TB];

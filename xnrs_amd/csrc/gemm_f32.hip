@@ -84,6 +84,7 @@ template <int TM, int TN, bool A_COL, bool B_KN, bool VEC, int PIPE, int BK, boo
           int KG = 2, bool RDOT = false>
 __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_tiles, int n_tiles_seg, int gn) {
   static_assert(!BUF || (!A_COL && !B_KN && VEC), "buffer loads are implemented for the forward layout");
+  static_assert(!RDOT || PIPE == 5, "the fused row dots ride on the interleaved pipeline (its MFMA call is the swapped one)");
   static_assert(!GATH || BUF, "the gathered-A variant keeps buffer loads for B");
   constexpr int BM = 64 * TM, BN = 64 * TN;
   // k-contiguous LDS tile rows: BK = 32 -> padded to 36 floats (conflict-free ds_read_b128, measured
@@ -497,7 +498,10 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kq & 1][i][e], fb[kq & 1][j][e], acc[i][j], 0, 0, 0);
+              if constexpr (RDOT)  // W . X^T: the block comes out transposed (tokens on the lanes), same fmaf chains
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[kq & 1][j][e], fa[kq & 1][i][e], acc[i][j], 0, 0, 0);
+              else
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kq & 1][i][e], fb[kq & 1][j][e], acc[i][j], 0, 0, 0);
           if (e == 1 && kq + 1 < NKQ) ldfrag((kq + 1) & 1, buf, kq + 1);
           if (slot >= 1 && slot < 1 + NCH) sstore(I0{}, buf ^ 1, slot - 1, t < last);  // tile t+1 -> LDS (redundant at the tail)
           if (slot >= 2 && slot < 2 + NCH) gload(I0{}, kn, slot - 2);        // tile t+2 -> the register just stored
@@ -533,27 +537,33 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
   const bool split = gridDim.y > 1;
   float* Cout = split ? a.slabs + (int64_t)blockIdx.y * a.slab_stride : a.C;
   if constexpr (RDOT) {
-    // fused row dots (GemmArgs::rowdot_w): v = act(acc + bias) * w[col], summed over the 32 columns of the MFMA block by
-    // a butterfly over the 32 lanes that hold them (xor 1..16 stays inside a 32-lane half); lane 0 of the half writes
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn * 32 * TN + 32 * j + ccol;
+    // fused row dots (GemmArgs::rowdot_w): the accumulators are TRANSPOSED blocks (see the MFMA call) -- lane l holds
+    // token row l & 31 and 16 of the block's 32 hidden units -- so the score of a block is an in-lane fmaf chain and one
+    // exchange with lane l ^ 32 (rowdot_block_t, kernels.h).  {bias, w} of this workgroup's columns are staged in LDS
+    // first (the K loop's last barrier has passed: the tile buffers are free).
+    float2* s_bw = reinterpret_cast<float2*>(&As[0][0]);
+    static_assert(sizeof(float2) * BN <= sizeof(float) * A_SZ * NBUF, "bias / weight staging fits the A tile buffers");
+    for (int c = tid; c < BN; c += 256) {
+      const int col = n0 + c;
       const bool cok = col < a.Nseg;
-      const float bv = (bias && cok) ? bias[col] : 0.f;
-      const float wv = cok ? a.rowdot_w[col] : 0.f;
-      const int slot = (n0 + wn * 32 * TN + 32 * j) >> 5;
+      s_bw[c] = make_float2((bias && cok) ? bias[col] : 0.f, cok ? a.rowdot_w[col] : 0.f);
+    }
+    __syncthreads();
+    const int half = lane >> 5;
+    auto dots = [&](auto FAST) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
+      for (int j = 0; j < TN; ++j) {
+        const int cb = wn * 32 * TN + 32 * j;  // first column of the block inside the tile
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          float v = apply_act(acc[i][j][e] + bv, a.act) * wv;
-#pragma unroll
-          for (int off = 1; off < 32; off <<= 1) v += __shfl_xor(v, off);
-          const int64_t row = m0 + wm * 32 * TM + 32 * i + (e & 3) + 8 * (e >> 2) + crow;
-          if (ccol == 0 && row < a.M && (n0 + wn * 32 * TN + 32 * j) < a.Nseg) a.rowdot_out[row * a.ldrd + slot] = v;
+        for (int i = 0; i < TM; ++i) {
+          const float sc = rowdot_block_t<decltype(FAST)::value>(acc[i][j], s_bw + cb, half);
+          const int64_t row = m0 + wm * 32 * TM + 32 * i + (lane & 31);
+          if (lane < 32 && row < a.M && n0 + cb < a.Nseg) a.rowdot_out[row * a.ldrd + ((n0 + cb) >> 5)] = sc;
         }
       }
-    }
+    };
+    if (a.act == ACT_TANH_FAST) dots(std::true_type{});
+    else dots(std::false_type{});
     return;
   }
 #pragma unroll
@@ -843,8 +853,9 @@ hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t stream, int* nsplit
   // kernel from HBM anyway: non-temporal stores keep it from evicting the operand panels (-0.5 % on the Q/K/V GEMM)
   a.nt_store = (!a.accumulate && !a.c_scatter && a.M * a.ldc * 4 >= (64ll << 20)) ? 1 : 0;
   if (a.colsum && !(a.a_col && a.b_kn)) return hipErrorInvalidValue;  // fused column sums: dW layout only
-  if (a.rowdot_out && (a.a_col || a.b_kn || a.nseg != 1 || nsplit != 1 || !a.rowdot_w || a.c_scatter || a.accumulate || a.aux_mode))
-    return hipErrorInvalidValue;  // fused row dots: plain forward launches only
+  if (a.rowdot_out && (a.a_col || a.b_kn || a.nseg != 1 || nsplit != 1 || !a.rowdot_w || a.c_scatter || a.accumulate || a.aux_mode ||
+                       (a.act != 2 && a.act != ACT_TANH_FAST)))
+    return hipErrorInvalidValue;  // fused row dots: plain forward launches with a tanh epilogue only (the pooler's fc1)
   hipError_t e;
   const int mode = gemm_mode();
   // the split kernel has one tile shape (128x128): below one full round of workgroups the fp32 kernel with its

@@ -209,6 +209,31 @@ __device__ __forceinline__ float fast_tanh(float x) {
   const float small = x * fmaf(x2, fmaf(x2, fmaf(x2, -17.f / 315.f, 2.f / 15.f), -1.f / 3.f), 1.f);
   return fabsf(x) < 0.125f ? small : big;
 }
+// The additive pooler's score, 32 hidden units at a time, from a TRANSPOSED accumulator block (the fc1 product taken as
+// W1 . X^T: v_mfma_f32_32x32x2_f32 with the operands swapped -- every element is the same fmaf chain as in X . W1^T):
+// lane l holds token row (l & 31) and the 16 hidden units 8 g + 4 (l >> 5) + r of the block (e = 4 g + r), so
+//   sum_h w2[h] tanh(acc[h] + b1[h])
+// is an IN-LANE chain of 16 fmaf plus ONE exchange with lane l ^ 32 (a + b on one side, b + a on the other: the same
+// bits).  The first version kept tokens on the accumulator rows and reduced over the 32 lanes that held a row's columns:
+// five ds_bpermute_b32 per ELEMENT (80 per block instead of 1) on the LDS pipe -- the whole difference between the
+// Q/K/V projection's 141 TF and the fc1 stage's 122 TF, and 80 of 250 us per tile in the fused additive encoder.
+// gemm_f32.hip (RDOT) and additive_fused.hip both call this, which is what keeps them bit-identical.
+// bw: b1 and w2 of the block's 32 hidden units, interleaved {b1[h], w2[h]} (zeros past A), in LDS or global memory.
+template <bool FAST>
+__device__ __forceinline__ float rowdot_block_t(const f32x16& acc, const float2* __restrict__ bw, int half) {
+  float s = 0.f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float2 c = bw[8 * g + 4 * half + r];
+      const float pre = acc[4 * g + r] + c.x;
+      s = fmaf(FAST ? fast_tanh(pre) : tanhf(pre), c.y, s);
+    }
+  }
+  return s + __shfl_xor(s, 32);
+}
+
 // activation codes inside the kernels: XNRS_ACT_* (0 none, 1 relu, 2 tanh) plus 3 = tanh through fast_tanh; the launchers
 // turn 2 into 3 when the knob is on
 constexpr int ACT_TANH_FAST = 3;
