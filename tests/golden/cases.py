@@ -78,6 +78,29 @@ GRAD = dict(model="NRMS", B=4, H=3, C=3, S=8, D=32, h=4, E=16, bias=False, seed=
             temperature=0.08, lambda_cl=0.1)
 
 
+# The same train step at the SHIPPED shape (config/mind_small_NRMS.yml: S=50, D=768, 16 heads -> d_k = 48, E=256): the
+# d_k = 48 / S = 50 backward kernels (mha_bwd_fused_kernel<3>, the live-row dW path) against the REAL reference.  The full
+# gradients are 12.6 MB, so tensors of more than GRAD_SAMPLE_MIN elements are stored as a fixed 4 096-element sample:
+# flat indices grad_sample_idx(numel) -- a multiplicative hash walk, the same on every machine.
+GRAD_SHIPPED = dict(model="NRMS", B=3, H=3, C=2, S=50, D=768, h=16, E=256, bias=False, seed=410, min_len=5,
+                    temperature=0.08, lambda_cl=0.1, themes=["theme1", "theme1", "theme0"])
+GRAD_SAMPLE_MIN, GRAD_SAMPLE_N = 8192, 4096
+
+
+def grad_sample_idx(numel: int):
+    """None: the tensor is stored whole; else int64 flat indices of the stored sample."""
+    if numel <= GRAD_SAMPLE_MIN:
+        return None
+    return (np.arange(GRAD_SAMPLE_N, dtype=np.int64) * 2654435761 + 12345) % numel
+
+
+def grad_sample(t):
+    """The stored view of a gradient tensor (numpy or torch): whole, or its fixed sample (flat)."""
+    a = t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
+    idx = grad_sample_idx(a.size)
+    return a if idx is None else a.reshape(-1)[idx]
+
+
 def model_cfg(c: dict) -> dict:
     """The flat YAML keys make_model reads, at the case's shape (one definition: xnrs_amd.synth.model_cfg)."""
     from xnrs_amd import synth

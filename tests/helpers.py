@@ -163,3 +163,22 @@ def assert_grads_close(grads, g, tol, prefix="grad/dW/"):
         assert e <= tol, f"{k}: {e:.3e} > {tol:.1e}"
         n += 1
     return n
+
+
+def assert_sampled_grads_close(grads, g, tol, prefix="gs/dW/", maxprefix="gs/max/"):
+    """assert_grads_close for the shipped-shape golden (tests/golden/cases.py GRAD_SHIPPED): big tensors are stored as a
+    fixed sample (cases.grad_sample), each with the max |.| of the WHOLE reference tensor as its scale."""
+    from tests.golden import cases
+    gmax = max(float(v) for k, v in g.items() if k.startswith(maxprefix))
+    n = 0
+    for k, got in grads.items():
+        if prefix + k not in g:
+            continue
+        ref = torch.as_tensor(g[prefix + k], dtype=torch.float64)
+        got = torch.as_tensor(cases.grad_sample(got), dtype=torch.float64)
+        assert got.shape == ref.shape, (k, got.shape, ref.shape)
+        scale = max(float(g[maxprefix + k]), 1e-3 * gmax)
+        e = (got - ref).abs().max().item() / scale
+        assert e <= tol, f"{k}: {e:.3e} > {tol:.1e}"
+        n += 1
+    return n

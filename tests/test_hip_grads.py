@@ -75,6 +75,39 @@ def test_train_step_matches_reference_golden():
     assert n >= 28
 
 
+@pytest.mark.parametrize("live", [True, False])
+def test_train_step_matches_reference_golden_shipped_shape(live, monkeypatch):
+    """The same train step at the SHIPPED shape (S=50, D=768, 16 heads: d_k = 48, E=256; cases.GRAD_SHIPPED): loss, input
+    gradients and all 28 parameter gradients of the REAL reference (whole, or a fixed 4 096-element sample of the big
+    tensors) -- mha_bwd_fused_kernel<3>, the folded out-projection backward and, with `live` (the threshold lowered so
+    this 250-row batch takes it), the live-row forward / dW path."""
+    from xnrs_amd import autograd
+    g = H.golden("grads_shipped")
+    c = cases.GRAD_SHIPPED
+    monkeypatch.setattr(autograd, "LIVE_ROWS", live)
+    monkeypatch.setattr(autograd, "LIVE_ROWS_MIN", 1)
+    model, sd = load(make_model(Cfg(cases.model_cfg(c))), c["seed"] + 1)
+    batch = cases.model_batch(c)
+    hx, hm = batch["user_features"]["history"]["title_emb"]
+    cx, cm = batch["candidate_features"]["title_emb"]
+    hx = hx.to(DEV).requires_grad_(True)
+    cx = cx.to(DEV).requires_grad_(True)
+    batch["user_features"]["history"]["title_emb"] = (hx, hm)
+    batch["candidate_features"]["title_emb"] = (cx, cm)
+    labels = cases.theme_labels(c["themes"]).to(DEV)
+    preds = torch.relu(model(batch))
+    loss_rec = torch.nn.functional.mse_loss(preds, batch["targets"].to(DEV))
+    loss_cl = contrastive_loss(model.get_user_embeddings(batch), labels, c["temperature"])  # the fused HIP InfoNCE
+    loss = loss_rec + c["lambda_cl"] * loss_cl
+    loss.backward()
+    H.assert_close(loss, g["gs/loss"], 1e-5)
+    H.assert_close(loss_cl, g["gs/loss_cl"], 1e-5)
+    H.assert_close(cases.grad_sample(hx.grad), g["gs/d_hist_x"], GTOL, "d_hist_x")
+    H.assert_close(cases.grad_sample(cx.grad), g["gs/d_cand_x"], GTOL, "d_cand_x")
+    n = H.assert_sampled_grads_close({k: p.grad for k, p in model.named_parameters() if p.grad is not None}, g, GTOL)
+    assert n >= 28
+
+
 @pytest.mark.parametrize("S,D,h", [(8, 32, 4), (30, 300, 15), (50, 64, 4), (9, 18, 3)])
 def test_mha_grads(S, D, h):
     att, sd = load(layers.MultiHeadAttention(h, D), 41)

@@ -4,3 +4,10 @@ Host side: Python on PyTorch-ROCm mirroring the reference's ``xnrs.models`` modu
 Device side: hand-written HIP kernels in ``libxnrs_hip.so`` (C ABI in include/xnrs_hip.h).
 """
 __version__ = "0.1.0"
+
+
+def install(force: bool = False) -> bool:
+    """Make the reference's own `from xnrs.models import make_model` (train.py:12) resolve to the HIP-backed modules
+    without touching a reference file -- see xnrs_amd/mirrors.py."""
+    from .mirrors import install as _install
+    return _install(force)

@@ -79,6 +79,7 @@ def _ref(s):
 #: XNRS_BWD_LIVE_ROWS=0 turns it off; it is used when at most LIVE_ROWS_MAX_FRACTION of the rows are unmasked.
 LIVE_ROWS = os.environ.get("XNRS_BWD_LIVE_ROWS", "1") != "0"
 LIVE_ROWS_MAX_FRACTION = 0.9
+LIVE_ROWS_MIN = 4096  # token rows from which the live-row path pays for its index bookkeeping (tests lower it)
 
 
 class _SeqEncode(torch.autograd.Function):
@@ -104,7 +105,7 @@ class _SeqEncode(torch.autograd.Function):
         # bookkeeping with torch (one host sync for the count); skipped when few rows are masked.
         live = live_src = None
         n_live = 0
-        if LIVE_ROWS and m is not None and cfg.n_heads > 0 and cfg.pool_kind == hip.POOL_ADDITIVE and n * L >= 4096:
+        if LIVE_ROWS and m is not None and cfg.n_heads > 0 and cfg.pool_kind == hip.POOL_ADDITIVE and n * L >= LIVE_ROWS_MIN:
             lm = (m[ids.long()] if ids is not None else m).reshape(-1).ne(0)
             rows_live = lm.nonzero().squeeze(1)
             if rows_live.numel() <= LIVE_ROWS_MAX_FRACTION * n * L:
