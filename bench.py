@@ -325,7 +325,7 @@ def other_models_extra(device, steps=5, warmup=2):
         batch = {"user_features": {"history": hist, "other": {}}, "candidate_features": cand}
         fn = lambda: model(batch)  # noqa: E731
         dt = timed(fn, steps, warmup, False) / steps
-        hip.profile_enable(0x3F)
+        hip.profile_enable(hip.PROFILE_ALL)
         r = fn()
         torch.cuda.synchronize()
         st = hip.profile_read()
@@ -357,6 +357,32 @@ def other_models_extra(device, steps=5, warmup=2):
     return out
 
 
+def train_roofline(fn, dt):
+    """Roofline entry of a grad step: EXECUTED matrix FLOPs of one step -- every GEMM / attention launch of the forward
+    and the backward counted by the library's launch timer with the row counts it really ran over (the live-row paths
+    contract over the unmasked token rows only) -- over the un-profiled step time `dt`, against the fp32 matrix peak;
+    and the dominant kernel family of the backward, the weight-gradient GEMMs (dW = dY^T . X), from hipEvents around
+    their launches (one extra, profiled step)."""
+    hip.profile_enable(hip.PROFILE_ALL)
+    fn()
+    torch.cuda.synchronize()
+    st = hip.profile_read()
+    hip.profile_enable(0)
+    total = sum(v[2] for v in st.values())
+    w_ms, w_n, w_fl = st["bwd_dw_gemms"]
+    ach = (w_fl / (w_ms * 1e-3) / 1e12) if w_ms > 0 else 0.0
+    return {"bound": "mfma", "achieved": total / dt / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": total / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, "executed_gflop_per_step": total / 1e9,
+            "what": "whole grad step: executed GEMM + attention FLOPs of forward and backward / step time (loss, optimizer and "
+                    "pooling kernels carry no matrix work and count as time only)",
+            "dominant_kernel": {"kernel": "weight-gradient GEMMs dW = dY^T.X (gemm_dw_kernel<KG> for live-row launches, "
+                                          "gemm_f32_kernel<2,2,true,true,...> k-major otherwise)",
+                                "achieved": ach, "frac": ach / FP32_MFMA_PEAK_TFLOPS, "launches_timed": w_n,
+                                "avg_launch_ms": w_ms / max(w_n, 1), "alg_flops_per_launch": w_fl / max(w_n, 1), "traffic": None},
+            "stage_ms_profiled_step": {k: round(v[0], 3) for k, v in st.items() if v[1]},
+            "stage_tflops": {k: (v[2] / (v[0] * 1e-3) / 1e12) for k, v in st.items() if v[0] > 0}}
+
+
 def train_step_extra(device, steps=5, warmup=2, model_name="NRMS", variants=True):
     """The grad step of the reference (training.py:402-431) on the HIP path: NRMS at the shipped
     config (batch 64, H=25, C=5, S=50, D=768, train-mode attention dropout 0.1), forward + relu/MSE +
@@ -382,6 +408,8 @@ def train_step_extra(device, steps=5, warmup=2, model_name="NRMS", variants=True
         return loss
     dt = timed(fn, steps, warmup, False) / steps
     out = dict(ms=dt * 1e3, impressions_per_s=w["B"] / dt, batch=w["B"], loss_finite=bool(torch.isfinite(fn()).item()))
+    assert out["loss_finite"], model_name
+    out["roofline"] = train_roofline(fn, dt)
     if not variants:
         return out
     # the same step with the empty history slots sharing one encoded representative (exact)
@@ -457,6 +485,38 @@ def eval_epoch_extra(device, n_news=20000, n_sess=20000):
     return dict(n_news=n_news, n_impressions=n_sess, candidates=int(beh.pos_off[-1] + beh.neg_off[-1]), seconds=dt,
                 impressions_per_s=n_sess / dt, auc=res["auc"],
                 unpadded=dict(seconds=dt_u, impressions_per_s=n_sess / dt_u, same_metrics=bool(res_u == res)))
+
+
+def store_upload_extra(device, n_news=4096):
+    """File -> HBM loader (NewsStore.load_to_device, replaces the pandas-pickle load of xnrs/data/mind.py:161-164): a
+    `n_news` x 50 x 768 fp32 store written to a RAM-backed temp dir (so the figure is the loader's pipeline -- memory map
+    -> two pinned staging buffers -> HBM -- not a disk), loaded twice (the second pass has warm page cache and pinned
+    pools), checked against the source."""
+    import shutil
+    import tempfile
+    from xnrs_amd.data import NewsStore
+    w = WORKLOAD
+    gen = torch.Generator(device=device)
+    gen.manual_seed(41)
+    tx, tm = synth.device_tokens(gen, n_news + 1, w["S"], w["D"], device)
+    store = NewsStore(tx, tm.reshape(n_news + 1, w["S"]), list(range(n_news)))
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="xnrs_store_", dir=base)
+    try:
+        path = os.path.join(d, "news")
+        store.save(path)
+        out = {}
+        for name in ("first_load", "second_load"):
+            st = {}
+            loaded = NewsStore.load_to_device(path, device, rows_per_chunk=1024, stats=st)
+            torch.cuda.synchronize()
+            out[name] = {"gb_per_s": st["gb_per_s"], "seconds": st["seconds"], "bytes": st["bytes"]}
+        out["equals_source"] = bool(torch.equal(loaded.x, store.x) and torch.equal(loaded.m, store.m))
+        out["where"] = "RAM-backed temp dir" if base else "temp dir on disk"
+        out["rows_per_chunk"] = 1024
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def gather_roofline(device, n_news=16384, n=512 * 55, reps=5):
@@ -549,7 +609,7 @@ def gemm_modes_extra(model, hist, cand, steps, scores_f32, cpu_sample):
         hip.set_gemm_mode(mode)
         fn = lambda: step(model, hist, cand)  # noqa: E731
         dt = timed(fn, steps, 2, False)
-        hip.profile_enable(0x3F)
+        hip.profile_enable(hip.PROFILE_ALL)
         r = fn()
         torch.cuda.synchronize()
         st = hip.profile_read()
@@ -677,7 +737,8 @@ def train_scaling(args, device, rank, world, dist_on):
         return loss
     dt = timed(fn, args.steps, args.warmup, dist_on)
     n_gpus = world if dist_on else 1
-    return {"metric": "train impressions/sec (forward + loss + backward + gradient all-reduce + Adam)",
+    roof = train_roofline(fn, dt / args.steps)  # every rank runs the profiled step (it contains the collectives)
+    return {"roofline": roof, "metric": "train impressions/sec (forward + loss + backward + gradient all-reduce + Adam)",
             "value": n_global * args.steps / dt, "unit": "impressions/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": GEMM_MODES[args.gemm_mode][0], "data": "synthetic",
@@ -873,7 +934,7 @@ def main():
         if n_gpus == 1 and not args.no_extra:
             with torch.no_grad():
                 out["extra"] = {"news_encoder_only_1024": news_only_extra(device)}
-                hip.profile_enable(0x3F)
+                hip.profile_enable(hip.PROFILE_ALL)
                 fn()
                 torch.cuda.synchronize()
                 st = hip.profile_read()
@@ -891,6 +952,7 @@ def main():
             out["extra"]["nrms_train_step_B64"] = train_step_extra(device)
             out["extra"]["standard_train_step_B64"] = train_step_extra(device, model_name="standard")
             out["extra"]["eval_epoch"] = eval_epoch_extra(device)
+            out["extra"]["store_file_to_hbm"] = store_upload_extra(device)
         assert torch.isfinite(scores).all()
         print(json.dumps(out))
     if dist_on:

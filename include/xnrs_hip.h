@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define XNRS_ABI_VERSION 2
+#define XNRS_ABI_VERSION 3
 
 #define XNRS_OK 0
 #define XNRS_EINVAL (-1)     /* bad shape / NULL pointer */
@@ -291,12 +291,21 @@ int32_t xnrs_infonce_bwd(const int64_t *labels, int64_t B, int32_t E, float temp
  * hipGraph-capturable while on).  stage_mask bit i selects stage i:
  *   0 qkv GEMM | 1 attention core | 2 out-proj GEMM | 3 fc1+tanh GEMM | 4 pooling | 5 head GEMMs
  *   6 fused short-sequence encoder (stages 0-4 in one launch: S <= 32, D <= 320, news_fused.hip)
+ *   7 weight-gradient GEMMs of the backward (dW = dY^T . X) | 8 input-gradient GEMMs (dX = dY . W)
+ *   9 attention-core backward
+ * (stage 3 also counts the one-launch additive encoder, additive_fused.hip: fc1 + pooling, stage 4 then stays empty)
  * xnrs_profile_read synchronises the recorded events and returns, per stage, the summed launch
  * duration (ms), the number of launches and the summed ALGORITHMIC flops of those launches
  * (arrays of XNRS_PROFILE_STAGES entries), then clears the record. */
-#define XNRS_PROFILE_STAGES 7
+#define XNRS_PROFILE_STAGES 10
 int32_t xnrs_profile_enable(uint32_t stage_mask);
 int32_t xnrs_profile_read(double *ms, int64_t *launches, double *flops);
+
+/* Does the TRAINING forward fold the out-projection behind the pooling right now (knob XNRS_FOLD_TRAIN)?
+ * The saved-activation blob of xnrs_seq_encoder_fwd_train* is laid out by that decision and xnrs_seq_encoder_bwd* reads it
+ * under the decision of ITS call time: a caller that may reload the knobs between the two (tests, A/B tools) records this
+ * value at the forward and refuses the backward when it has changed (xnrs_amd/autograd.py does).  1 / 0. */
+int32_t xnrs_train_fold_enabled(void);
 
 /* ---- arithmetic mode of the forward GEMMs (nn.Linear call sites listed at xnrs_linear_fwd) ----------
  *   XNRS_GEMM_F32     (0, default) v_mfma_f32_32x32x2_f32: an exact fp32 fmaf chain.

@@ -107,7 +107,7 @@ def test_default_dispatch_takes_the_fused_kernel_from_a_full_chip_on():
     enc, _ = encoder(D, A, 256, True, False, 5)
     for n, fused in ((3835, False), (3836, True)):  # 767 and 768 tiles of 5 news
         x, m = tokens(n, S, D, 6, full_pad_prob=0.0)
-        hip.profile_enable(0x3F)
+        hip.profile_enable(hip.PROFILE_ALL)
         with torch.no_grad():
             y, _ = ops.text_encoder_forward(x, m, None, enc.pooler, enc.head)
         torch.cuda.synchronize()

@@ -39,7 +39,7 @@ def build(S, D, h, E, seed):
 
 
 def stages_used(fn):
-    hip.profile_enable(0x7F)
+    hip.profile_enable(hip.PROFILE_ALL)
     out = fn()
     torch.cuda.synchronize()
     st = hip.profile_read()

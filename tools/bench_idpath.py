@@ -36,6 +36,6 @@ with torch.no_grad():
             res[name].append(bench.timed(fn, 5, 2, False) / 5 * 1e3)
     print({k: [round(x, 2) for x in v] for k, v in res.items()})
     for name, fn in (("ids", fa), ("dense", fb), ("seq_ids", fc)):
-        hip.profile_enable(0x7F); fn(); torch.cuda.synchronize(); st = hip.profile_read(); hip.profile_enable(0)
+        hip.profile_enable(hip.PROFILE_ALL); fn(); torch.cuda.synchronize(); st = hip.profile_read(); hip.profile_enable(0)
         print(name, {k: round(v[0], 3) for k, v in st.items()})
     print("equal", torch.equal(fa(), fb()), torch.equal(fc(), fb()))

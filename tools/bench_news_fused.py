@@ -38,7 +38,7 @@ for (n_news, S, D, h) in shapes:
                     torch.cuda.synchronize()
                     res[flag].append((time.perf_counter() - t0) / 20)
         with hip.knobs(XNRS_NEWS_FUSED="2"):
-            hip.profile_enable(0x7F)
+            hip.profile_enable(hip.PROFILE_ALL)
             for _ in range(10):
                 model.news_encoder((x, m))
             torch.cuda.synchronize()

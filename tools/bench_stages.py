@@ -36,7 +36,7 @@ with torch.no_grad():
             for _ in range(2):
                 model.news_encoder((x, m))
             torch.cuda.synchronize()
-            hip.profile_enable(0x3F)
+            hip.profile_enable(hip.PROFILE_ALL)
             for _ in range(3):
                 model.news_encoder((x, m))
             torch.cuda.synchronize()

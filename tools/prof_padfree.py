@@ -29,7 +29,7 @@ with torch.no_grad():
             bench.step(model, hist, cand)
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) / 5 * 1e3
-        hip.profile_enable(0x3F)
+        hip.profile_enable(hip.PROFILE_ALL)
         bench.step(model, hist, cand)
         torch.cuda.synchronize()
         st = hip.profile_read()

@@ -118,6 +118,7 @@ class _SeqEncode(torch.autograd.Function):
                                                     nsaved, hip.ptr(live), hip.ptr(live_src), n_live, hip.stream_ptr(dev)),
                   "xnrs_seq_encoder_fwd_train_live")
         ctx.live, ctx.live_src, ctx.n_live = live, live_src, n_live
+        ctx.fold = l.xnrs_train_fold_enabled()  # the saved blob is laid out by this decision (include/xnrs_hip.h)
         ctx.cfg = cfg
         ctx.nsaved = nsaved
         ctx.n_params = len(params)
@@ -158,6 +159,9 @@ class _SeqEncode(torch.autograd.Function):
             gh = hip.HeadGrads(*[None if g is None else g.data_ptr() for g in grads[i:i + 4]])
             i += 4
         l = hip.lib()
+        if l.xnrs_train_fold_enabled() != ctx.fold:
+            raise hip.XnrsHipError("XNRS_FOLD_TRAIN changed between a training forward and its backward: the saved "
+                                   "activations were laid out for the other setting (reload the knobs outside a step)")
         nws = l.xnrs_seq_encoder_bwd_workspace_bytes(n, L, D, cfg.A, Eo, cfg.n_heads, cfg.pool_kind, int(cfg.has_head))
         ws = hip.workspace(dev, nws)
         live, live_src, n_live = ctx.live, ctx.live_src, ctx.n_live  # the unmasked rows found by the forward

@@ -803,6 +803,8 @@ int32_t xnrs_set_gemm_mode(int32_t mode) {
 
 int32_t xnrs_get_gemm_mode(void) { return xnrs::gemm_mode(); }
 
+int32_t xnrs_train_fold_enabled(void) { return fold_wanted(knobs().fold_train) ? 1 : 0; }
+
 int32_t xnrs_reload_knobs(void) {
   xnrs::reload_knobs();
   return XNRS_OK;
@@ -962,6 +964,7 @@ hipError_t gemm_dw(const float* dY, int64_t lddy, const float* X, const int32_t*
   const bool fuse_db = db && csum && (lddy % 4 == 0) && (N % 4 == 0);  // the k-major vector path stages dY as 16-byte chunks
   if (fuse_db) g.colsum = csum;
   int nsplit_used = 1;
+  ProfScope ps(7, 2.0 * (double)M * N * K, stream);  // M = the rows actually contracted (the live ones)
   hipError_t e = launch_gemm_f32(g, stream, &nsplit_used);
   if (e != hipSuccess) return e;
   if (fuse_db) return launch_colsum_final(csum, nsplit_used, N, db, stream);
@@ -996,6 +999,7 @@ hipError_t gemm_dx(const float* dY, int64_t lddy, const float* W, float* dX, int
   g.ldaux = ldaux;
   g.aux_mode = aux_mode;
   g.accumulate = accumulate;
+  ProfScope ps(8, 2.0 * (double)M * N * K, stream);
   if (wt_scratch && M >= 4096) {
     hipError_t e = launch_transpose(W, wt_scratch, N, K, stream);  // Wt[K][N]
     if (e != hipSuccess) return e;
@@ -1264,7 +1268,10 @@ int32_t xnrs_seq_encoder_bwd_live(const float* x, const float* m, const int32_t*
   mb.dropout_p = att->dropout_p;
   mb.seed = att->seed;
   mb.masked_do_is_zero = (pooled && m) ? 1 : 0;  // both poolers give masked rows a zero gradient
-  XNRS_TRY(launch_mha_bwd(mb, stream));
+  {
+    ProfScope ps(9, 10.0 * rows * (double)L * D, stream);  // S, dP, dV, dK, dQ: five S x S x d_k products per head
+    XNRS_TRY(launch_mha_bwd(mb, stream));
+  }
   // ---- Q/K/V projections
   float* gw[3] = {g_att ? g_att->wq : nullptr, g_att ? g_att->wk : nullptr, g_att ? g_att->wv : nullptr};
   float* gb[3] = {g_att ? g_att->bq : nullptr, g_att ? g_att->bk : nullptr, g_att ? g_att->bv : nullptr};

@@ -31,10 +31,12 @@ SYMBOLS = (
     "xnrs_seq_encoder_bwd", "xnrs_seq_encoder_bwd_live", "xnrs_linear_bwd_workspace_bytes", "xnrs_linear_bwd",
     "xnrs_embedding_linear_bwd_workspace_bytes", "xnrs_embedding_linear_bwd", "xnrs_dot_scoring_bwd", "xnrs_dot_scoring_norm_bwd",
     "xnrs_assemble_train_batch", "xnrs_assemble_eval_batch", "xnrs_score_csr", "xnrs_rank_metrics", "xnrs_gather_rows",
-    "xnrs_infonce_saved_bytes", "xnrs_infonce_fwd", "xnrs_infonce_bwd",
+    "xnrs_infonce_saved_bytes", "xnrs_infonce_fwd", "xnrs_infonce_bwd", "xnrs_train_fold_enabled",
 )
 POOL_NONE = -1
-PROFILE_STAGES = ("qkv_gemm", "attention_core", "out_gemm", "fc1_tanh_gemm", "pool", "head_gemms", "news_fused")
+PROFILE_STAGES = ("qkv_gemm", "attention_core", "out_gemm", "fc1_tanh_gemm", "pool", "head_gemms", "news_fused",
+                  "bwd_dw_gemms", "bwd_dx_gemms", "bwd_attention_core")
+PROFILE_ALL = (1 << len(PROFILE_STAGES)) - 1
 
 
 class XnrsHipError(RuntimeError):
@@ -171,7 +173,9 @@ def lib():
     l.xnrs_profile_enable.argtypes = [C.c_uint32]
     l.xnrs_profile_read.restype = i32
     l.xnrs_profile_read.argtypes = [p, p, p]
-    if l.xnrs_abi_version() != 2:
+    l.xnrs_train_fold_enabled.restype = i32
+    l.xnrs_train_fold_enabled.argtypes = []
+    if l.xnrs_abi_version() != 3:
         raise XnrsHipError("libxnrs_hip.so ABI version mismatch; rebuild it")
     _lib = l
     return l
