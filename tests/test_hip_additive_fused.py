@@ -101,11 +101,11 @@ def test_fused_reproduces_the_reference_goldens(name):
 
 
 def test_default_dispatch_takes_the_fused_kernel_from_a_full_chip_on():
-    """Default knob: >= 768 tiles (three per CU) -> the fused launch (profile stage 3 records ONE launch and no pooling
+    """Default knob: >= 512 tiles (two per CU) -> the fused launch (profile stage 3 records ONE launch and no pooling
     launch), fewer -> the pipeline; the results agree bit for bit either way."""
     S, D, A = 50, 768, 256
     enc, _ = encoder(D, A, 256, True, False, 5)
-    for n, fused in ((3835, False), (3836, True)):  # 767 and 768 tiles of 5 news
+    for n, fused in ((2555, False), (2556, True)):  # 511 and 512 tiles of 5 news
         x, m = tokens(n, S, D, 6, full_pad_prob=0.0)
         hip.profile_enable(hip.PROFILE_ALL)
         with torch.no_grad():
@@ -113,7 +113,10 @@ def test_default_dispatch_takes_the_fused_kernel_from_a_full_chip_on():
         torch.cuda.synchronize()
         st = hip.profile_read()
         hip.profile_enable(0)
-        assert (st["pool"][1] == 0) == fused and st["fc1_tanh_gemm"][1] == 1, (n, st)
+        if fused:
+            assert st["pool"][1] == 0 and st["fc1_tanh_gemm"][1] == 1, (n, st)
+        else:  # the pipeline: one fc1 GEMM and one pooling launch per 65 500-row pass
+            assert st["pool"][1] == st["fc1_tanh_gemm"][1] >= 1, (n, st)
         y0, _ = run(enc, x, m, "0")
         assert torch.equal(y, y0)
 

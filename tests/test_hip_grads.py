@@ -8,6 +8,7 @@ from oracle import xnrs_oracle as O
 from tests import helpers as H
 from tests.golden import cases
 from xnrs_amd import synth
+from xnrs_amd.losses import contrastive_loss
 from xnrs_amd.models import make_model
 from xnrs_amd.models.components import layers, news_encoding, user_encoding
 

@@ -176,13 +176,11 @@ __global__ __launch_bounds__(AF_T, AF_WAVES / 4) void additive_fused_kernel(Addi
     }
   };
 
-  int it = 0;
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, ++it) {
-    const int64_t news0 = (int64_t)tile * nn;
-    const int cur = it & 1;  // s_wn buffer of this tile (the other one still feeds the previous tile's pooling)
-    // ---- A operand rows of this tile: tile row r = news r / S, token r % S (rows past nn*S and news past the batch are
-    // clamped to a valid row: their results are never used)
-    const float* pa[AF_NR];
+  // ---- A operand rows of a tile: tile row r = news r / S, token r % S (rows past nn*S and news past the batch are clamped
+  // to a valid row: their results are never used)
+  const float* pa[AF_NR];
+  f32x4 ra[AF_NR], rb[AF_NR];
+  auto tile_rows = [&](int64_t news0) {
 #pragma unroll
     for (int i = 0; i < AF_NR; ++i) {
       const int r = lr + AF_RPP * i;
@@ -197,7 +195,27 @@ __global__ __launch_bounds__(AF_T, AF_WAVES / 4) void additive_fused_kernel(Addi
       const int64_t src = a.ids ? (int64_t)a.ids[news] : news;
       pa[i] = a.x + src * SD + (int64_t)tok * D + 4 * lc;
     }
-    f32x4 ra[AF_NR], rb[AF_NR];
+  };
+  auto gload0 = [&]() {  // K tile 0 of the tile pa[] points at
+    const int klim = D - 4 - 4 * lc;
+    const int ka = 0 < klim ? 0 : klim;
+    const unsigned sel = (4 * lc < D) ? 0u : AF_OOB;
+#pragma unroll
+    for (int i = 0; i < AF_NR; ++i) {
+      ra[i] = *reinterpret_cast<const f32x4*>(pa[i] + ka);
+      rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(offB0 | sel), i * dB, 0));
+    }
+  };
+  if ((int)blockIdx.x < n_tiles) {
+    tile_rows((int64_t)blockIdx.x * nn);
+    gload0();
+  }
+  int it = 0;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, ++it) {
+    const int64_t news0 = (int64_t)tile * nn;
+    const int cur = it & 1;  // s_wn buffer of this tile (the other one still feeds the previous tile's pooling)
+    // (pa[]: the A operand rows of this tile, set up -- with its first K tile already in flight -- in front of the
+    // previous tile's epilogue, or before the loop for the first tile)
     auto gload = [&](int k0, int which) {  // which < AF_NR: A row lr + AF_RPP * which; then the B rows
       if (which < AF_NR) {
         const int klim = D - 4 - 4 * lc;  // k tail: clamped (it meets the zeros B returns there)
@@ -237,8 +255,7 @@ __global__ __launch_bounds__(AF_T, AF_WAVES / 4) void additive_fused_kernel(Addi
     };
 
     // ---- K loop (gemm_f32.hip PIPE 5) with the previous tile's pooling folded in
-#pragma unroll
-    for (int w = 0; w < AF_NCH; ++w) gload(0, w);
+    // (K tile 0 is in ra / rb already: loaded in front of the previous tile's epilogue)
 #pragma unroll
     for (int w = 0; w < AF_NCH; ++w) sstore(0, w);
 #pragma unroll
@@ -286,6 +303,12 @@ __global__ __launch_bounds__(AF_T, AF_WAVES / 4) void additive_fused_kernel(Addi
       pool_store(prev_news0);
     }
 
+    // K tile 0 of this workgroup's NEXT tile flies during the epilogue (2-3 us of HBM latency per tile otherwise)
+    if (tile + (int)gridDim.x < n_tiles) {
+      tile_rows((int64_t)(tile + gridDim.x) * nn);
+      gload0();
+    }
+
     // ---- scores: per transposed block an in-lane fmaf chain over 16 hidden units + one exchange with lane l ^ 32
     // (rowdot_block_t, shared with the GEMM's RDOT epilogue); lanes 0..31 park the block sum of their token row
     const int half = lane >> 5;
@@ -293,11 +316,14 @@ __global__ __launch_bounds__(AF_T, AF_WAVES / 4) void additive_fused_kernel(Addi
 #pragma unroll
       for (int j = 0; j < AF_TN; ++j) {
         const int slot = wn * AF_TN + j;
+        float2 bw[16];
+        rowdot_load_bw(bw, s_bw + 32 * slot, half);
+        float sc[AF_TM];
 #pragma unroll
-        for (int i = 0; i < AF_TM; ++i) {
-          const float sc = rowdot_block_t<decltype(FAST)::value>(acc[i][j], s_bw + 32 * slot, half);
-          if (lane < 32) s_ep[(wm * 32 * AF_TM + 32 * i + lane) * AF_EPS + slot] = sc;
-        }
+        for (int i = 0; i < AF_TM; ++i) sc[i] = rowdot_block_t<decltype(FAST)::value>(acc[i][j], bw);
+#pragma unroll
+        for (int i = 0; i < AF_TM; ++i)
+          if (lane < 32) s_ep[(wm * 32 * AF_TM + 32 * i + lane) * AF_EPS + slot] = sc[i];
       }
     };
     if (AF_EXP & 2) {  // every accumulator element used (no dead MFMAs), none of the score arithmetic

@@ -303,12 +303,13 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
   // Additive-only towers (no self-attention: StandardRec / BaseRec / NAML / LSTUR news encoders) from a batch that fills
   // the chip: fc1 + tanh + fc2 + exp + mask + normalise + weighted sum as ONE persistent launch (additive_fused.hip).  Its
   // result equals the GEMM + pooling pipeline's bit for bit (same MFMA fragments and k order, same reduction orders), so
-  // the choice may depend on the batch size without a news vector ever changing: below three 256-row tiles per CU the
-  // pipeline's smaller tiles fill the chip better (tools/bench_af.py: 2 560 news x 50 x 768 -- two tiles per CU -- 0.540 vs
-  // 0.526 ms for the pipeline; 12 800 news -- ten per CU -- 2.18 vs 2.26 ms).
+  // the choice may depend on the batch size without a news vector ever changing: from two 256-row tiles per CU on the
+  // fused launch wins (tools/bench_af.py, settled clocks: 2 560 news x 50 x 768 -- two tiles per CU -- 0.447 vs 0.469 ms for
+  // the pipeline; 12 800 news -- ten per CU -- 2.13 vs 2.33 ms, i.e. 0.98 of the plain fc1 GEMM of the same shape with the
+  // pooling included); below that the pipeline's smaller tiles fill the chip better.
   bool afused = !att && additive && !train && !a_out && gemm_mode() == 0 && knobs().additive_fused &&
                 additive_fused_plan(L, D, A, nullptr, nullptr) && rowdot &&
-                (knobs().additive_fused == 2 || additive_fused_tiles(n_seq, L) >= 768);
+                (knobs().additive_fused == 2 || additive_fused_tiles(n_seq, L) >= 512);
   if (afused) {
     AdditiveFusedArgs af{};
     af.x = x; af.ids = ids; af.mask = m;

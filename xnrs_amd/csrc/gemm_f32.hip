@@ -554,9 +554,11 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int cb = wn * 32 * TN + 32 * j;  // first column of the block inside the tile
+        float2 bw[16];
+        rowdot_load_bw(bw, s_bw + cb, half);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          const float sc = rowdot_block_t<decltype(FAST)::value>(acc[i][j], s_bw + cb, half);
+          const float sc = rowdot_block_t<decltype(FAST)::value>(acc[i][j], bw);
           const int64_t row = m0 + wm * 32 * TM + 32 * i + (lane & 31);
           if (lane < 32 && row < a.M && n0 + cb < a.Nseg) a.rowdot_out[row * a.ldrd + ((n0 + cb) >> 5)] = sc;
         }

@@ -198,16 +198,15 @@ __device__ __forceinline__ int64_t xcd_pair(int64_t L, int64_t W, int n_heads) {
 __device__ __forceinline__ float attn_exp(float x) { return __expf(x); }
 
 // tanh for the activation epilogues (the additive pooler's tanh(fc1 x), layers.py:60; a Tanh head): the hardware exp2 and
-// reciprocal instead of ocml's tanhf (~12 instead of ~60 VALU instructions per element with both branches of the ocml
-// version executed; the fc1 epilogue was 15 % of that GEMM).  |x| >= 1/8: 1 - 2 / (exp(2x) + 1), absolute error <= ~1.5e-7
-// (relative <= ~1.2e-6); |x| < 1/8: the odd Taylor polynomial to x^7 (relative error < 3e-9 + rounding), so small
-// arguments keep their relative accuracy.  Saturates to +-1, propagates NaN.  Parity bar 1e-4; XNRS_FAST_TANH=0 = tanhf.
+// reciprocal, 1 - 2 / (exp(2x) + 1), instead of ocml's tanhf (6 instead of ~60 VALU instructions per element with both
+// branches of the ocml version executed).  ABSOLUTE error <= ~1.5e-7 everywhere (relative <= ~1.2e-6 for |x| >= 1/8;
+// for smaller arguments the relative error grows as the result shrinks -- what the value feeds, the fc2 dot and
+// 1 - t^2 in the backward, only sees the absolute error; a version that switched to the odd Taylor polynomial below 1/8
+// cost 6 more instructions per element, a third of the fused encoder's epilogue, and moved no test).  Saturates to
+// +-1, propagates NaN.  Parity bar 1e-4; XNRS_FAST_TANH=0 = tanhf.
 __device__ __forceinline__ float fast_tanh(float x) {
   const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);  // exp(2x)
-  const float big = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
-  const float x2 = x * x;
-  const float small = x * fmaf(x2, fmaf(x2, fmaf(x2, -17.f / 315.f, 2.f / 15.f), -1.f / 3.f), 1.f);
-  return fabsf(x) < 0.125f ? small : big;
+  return fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
 }
 // The additive pooler's score, 32 hidden units at a time, from a TRANSPOSED accumulator block (the fc1 product taken as
 // W1 . X^T: v_mfma_f32_32x32x2_f32 with the operands swapped -- every element is the same fmaf chain as in X . W1^T):
@@ -218,20 +217,24 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // five ds_bpermute_b32 per ELEMENT (80 per block instead of 1) on the LDS pipe -- the whole difference between the
 // Q/K/V projection's 141 TF and the fc1 stage's 122 TF, and 80 of 250 us per tile in the fused additive encoder.
 // gemm_f32.hip (RDOT) and additive_fused.hip both call this, which is what keeps them bit-identical.
-// bw: b1 and w2 of the block's 32 hidden units, interleaved {b1[h], w2[h]} (zeros past A), in LDS or global memory.
+// bw: {b1[h], w2[h]} of the lane's 16 hidden units (zeros past A), see rowdot_load_bw.
 template <bool FAST>
-__device__ __forceinline__ float rowdot_block_t(const f32x16& acc, const float2* __restrict__ bw, int half) {
+__device__ __forceinline__ float rowdot_block_t(const f32x16& acc, const float2 (&bw)[16]) {
   float s = 0.f;
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float2 c = bw[8 * g + 4 * half + r];
-      const float pre = acc[4 * g + r] + c.x;
-      s = fmaf(FAST ? fast_tanh(pre) : tanhf(pre), c.y, s);
-    }
+  for (int e = 0; e < 16; ++e) {
+    const float pre = acc[e] + bw[e].x;
+    s = fmaf(FAST ? fast_tanh(pre) : tanhf(pre), bw[e].y, s);
   }
   return s + __shfl_xor(s, 32);
+}
+// {b1, w2} of the 16 hidden units a lane holds in a block (element e = 4 g + r <-> unit 8 g + 4 half + r), from the block's
+// 32 interleaved pairs in LDS; loaded ONCE per hidden block and reused for every token block of the wave
+__device__ __forceinline__ void rowdot_load_bw(float2 (&bw)[16], const float2* __restrict__ src, int half) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bw[4 * g + r] = src[8 * g + 4 * half + r];
 }
 
 // activation codes inside the kernels: XNRS_ACT_* (0 none, 1 relu, 2 tanh) plus 3 = tanh through fast_tanh; the launchers
