@@ -423,15 +423,17 @@ def test_backward_over_live_rows_matches_dense_backward(with_ids):
         assert check_param_grads(enc, osd) >= 12
 
 
+@pytest.mark.parametrize("D", [96, 448])
 @pytest.mark.parametrize("with_ids", [False, True])
 @pytest.mark.parametrize("live", [False, True])
-def test_weight_gradient_kernels_agree(with_ids, live):
-    """The register-transposing weight-gradient kernel (gemm_dw.hip; XNRS_GEMM_DW=2 sends every eligible launch to
-    it: dense rows, live-row lists, table-gathered X) against the generic k-major kernel (XNRS_GEMM_DW=0) on a
-    contraction long enough to qualify (>= 8192 rows), widths that leave a ragged 128-tile, and a split-K count that
-    is not a multiple of the 8 XCDs."""
+def test_weight_gradient_kernels_agree(with_ids, live, D):
+    """The register-transposing weight-gradient kernels (gemm_dw.hip; XNRS_GEMM_DW=3 sends every eligible launch to
+    them: dense rows, live-row lists, table-gathered X) against the generic k-major kernel (XNRS_GEMM_DW=0) on a
+    contraction long enough to qualify (>= 8192 rows), widths that leave a ragged tile (D = 96: the 128 x 128 tile;
+    D = 448 = 256 + 192: the 256 x 256 tile, and with XNRS_GEMM_DW_TILE=128 the small one on the same shapes), and
+    a split-K count that is not a multiple of the 8 XCDs."""
     from xnrs_amd import autograd as AG, hip
-    S, D, h, E = 24, 96, 4, 32
+    S, h, E = 24, 4, 32
     enc, sd = load(news_encoding.TextEncoder(pooler=layers.AdditiveAttention(D, 80), p_dropout=0.0, out_features=E,
                                              in_features=D, att=layers.MultiHeadAttention(h, D)), 181)
     rng = synth.rng_for(182)
@@ -442,8 +444,8 @@ def test_weight_gradient_kernels_agree(with_ids, live):
     w = torch.from_numpy(rng.standard_normal((n_news if with_ids else n_tab, E)).astype("float32")).to(DEV)
     ids = torch.from_numpy(rng.integers(0, n_tab, size=(n_news,)).astype("int64")) if with_ids else None
 
-    def run(knob):
-        with hip.knobs(XNRS_GEMM_DW=knob):
+    def run(knob, tile="256"):
+        with hip.knobs(XNRS_GEMM_DW=knob, XNRS_GEMM_DW_TILE=tile):
             AG.LIVE_ROWS = live
             try:
                 enc.zero_grad(set_to_none=True)
@@ -457,12 +459,13 @@ def test_weight_gradient_kernels_agree(with_ids, live):
                 AG.LIVE_ROWS = True
         return {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None}
 
-    g0, g2 = run("0"), run("2")
-    assert g0.keys() == g2.keys() and len(g0) >= 12
+    g0 = run("0")
     gmax = max(v.abs().max().item() for v in g0.values())
-    for k in g0:  # (the key bias gradient is exactly zero in exact arithmetic: softmax shift invariance -> floor the scale)
-        scale = max(g0[k].abs().max().item(), 1e-3 * gmax)
-        assert (g2[k] - g0[k]).abs().max().item() / scale <= 2e-5, f"{k}: gemm_dw vs k-major kernel"
+    for g2 in ([run("3")] if D < 384 else [run("3"), run("3", "128"), run("2")]):
+        assert g0.keys() == g2.keys() and len(g0) >= 12
+        for k in g0:  # (the key bias gradient is exactly zero in exact arithmetic: softmax shift invariance -> floor the scale)
+            scale = max(g0[k].abs().max().item(), 1e-3 * gmax)
+            assert (g2[k] - g0[k]).abs().max().item() / scale <= 2e-5, f"{k}: gemm_dw vs k-major kernel"
     if not with_ids:
         osd = oracle_sd(sd)
         yo, _ = O.text_encoder(x.unsqueeze(0), m.reshape(1, n_tab, S, 1), osd, h)

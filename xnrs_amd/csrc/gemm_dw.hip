@@ -30,6 +30,21 @@ __device__ __attribute__((aligned(16))) float g_dw_zero[4] = {0.f, 0.f, 0.f, 0.f
 
 constexpr int DW_BM = 128, DW_BN = 128, DW_BK = 16;
 
+// LDS image of an operand tile: [i][16 k] as 64-byte rows of four 16-byte chunks -- with the rows PERMUTED inside groups
+// of four and the chunk index swizzled so that BOTH access patterns are conflict-free.  Write r = 16 a + 4 b + d (d = r & 3,
+// b = (r >> 2) & 3); a 16-byte slot's bank group is 4 (physical row & 3) + physical chunk, 16 groups in all.
+//   physical row   = (r & ~3) | ((d + b) & 3)
+//   physical chunk = c ^ ((b + a) & 3)
+// Fragment read (16 lanes = 16 consecutive rows, a fixed, one logical chunk): (b, d) -> ((d + b) & 3, (b + a) & 3) is a
+// bijection: 16 distinct groups.  Transposed store (16 lanes = one column d of 16 consecutive 4 x 4 blocks, rows 4 c4 + d:
+// b = c4 & 3, a = c4 >> 2): (b, a & 3) -> ((d + b) & 3, (b + a) & 3) is a bijection too.  The first layout swizzled the
+// chunk by (r >> 2) & 3 only: every lane of a store instruction then shared r & 3 = d and landed in 4 of the 16 groups --
+// SQ_LDS_BANK_CONFLICT was 29 % of the LDS cycles of these kernels (profiles/r03_train_step_pmc.txt).
+__device__ __forceinline__ int dw_lds_off(int row, int chunk) {  // float offset of (row, logical chunk) inside a tile image
+  const int d = row & 3, b = (row >> 2) & 3, a = row >> 4;
+  return ((row & ~3) | ((d + b) & 3)) * DW_BK + 4 * (chunk ^ ((b + a) & 3));
+}
+
 template <int KG>
 __global__ __launch_bounds__(256, 3) void gemm_dw_kernel(GemmArgs a, int n_tiles, int tiles, int nsplit) {
   __shared__ __attribute__((aligned(16))) float As[2][DW_BM * DW_BK];
@@ -68,10 +83,7 @@ __global__ __launch_bounds__(256, 3) void gemm_dw_kernel(GemmArgs a, int n_tiles
   // transposed store: column e' of the block = row 4 c4 + e' of the LDS image, chunk kb (swizzled)
   int soff[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int row = 4 * c4 + e;
-    soff[e] = row * DW_BK + 4 * (kb ^ ((row >> 2) & 3));
-  }
+  for (int e = 0; e < 4; ++e) soff[e] = dw_lds_off(4 * c4 + e, kb);
 
   const bool do_cs = a.colsum != nullptr && nt == 0 && !isB;
   f32x4 cs = {0.f, 0.f, 0.f, 0.f};
@@ -115,14 +127,8 @@ __global__ __launch_bounds__(256, 3) void gemm_dw_kernel(GemmArgs a, int n_tiles
 
   const int frow = lane & 31, fc = lane >> 5;
   const int a_row0 = wm * 64 + frow, b_row0 = wn * 64 + frow;
-  auto fraga = [&](int buf, int kq, int i) {
-    const int row = a_row0 + 32 * i;
-    return *reinterpret_cast<const f32x4*>(&As[buf][row * DW_BK + 4 * ((kq * 2 + fc) ^ ((row >> 2) & 3))]);
-  };
-  auto fragb = [&](int buf, int kq, int j) {
-    const int row = b_row0 + 32 * j;
-    return *reinterpret_cast<const f32x4*>(&Bs[buf][row * DW_BK + 4 * ((kq * 2 + fc) ^ ((row >> 2) & 3))]);
-  };
+  auto fraga = [&](int buf, int kq, int i) { return *reinterpret_cast<const f32x4*>(&As[buf][dw_lds_off(a_row0 + 32 * i, kq * 2 + fc)]); };
+  auto fragb = [&](int buf, int kq, int j) { return *reinterpret_cast<const f32x4*>(&Bs[buf][dw_lds_off(b_row0 + 32 * j, kq * 2 + fc)]); };
 
   const int nk = (kend - kbeg + DW_BK - 1) / DW_BK;
   const int last = nk - 1;
@@ -206,6 +212,164 @@ __global__ __launch_bounds__(256, 3) void gemm_dw_kernel(GemmArgs a, int n_tiles
   }
 }
 
+// ---- the same product on 256 x 256 tiles: 8 waves (2 per SIMD, <= 256 registers) of 128 x 64 each, ONE workgroup per CU.
+// A 128 x 128 tile moves 16 KB of operands per 16-deep K step for 0.5 MFLOP (32 FLOP per byte staged: ~19 GB/s per CU at
+// the matrix peak, twice what the per-CU load path sustained in the forward GEMMs); the 256 x 256 tile stages 32 KB per
+// 2.1 MFLOP.  Same transposing register stage (threads 0-255 stage dY, 256-511 stage X: a 16 x 256 tile is 256 blocks of
+// 4 x 4), same swizzled [i][16 k] LDS image, one register set, stores behind MFMA slots 0-3 and reloads behind 4-7; the
+// MFMA loop is additive_fused.hip's (6 fragment reads per 32 MFMAs).
+constexpr int DW2_BM = 256, DW2_BN = 256;
+
+template <int KG>
+__global__ __launch_bounds__(512, 2) void gemm_dw256_kernel(GemmArgs a, int n_tiles, int tiles, int nsplit) {
+  __shared__ __attribute__((aligned(16))) float As[2][DW2_BM * DW_BK];
+  __shared__ __attribute__((aligned(16))) float Bs[2][DW2_BN * DW_BK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves
+  int w;
+  {  // XCD-contiguous, split-major work list (see gemm_dw_kernel)
+    const int L = blockIdx.x, W = tiles * nsplit, x = L & 7, q = L >> 3, per = W >> 3, rem = W & 7;
+    w = per * x + (x < rem ? x : rem) + q;
+  }
+  const int split = w / tiles, tile = w - split * tiles;
+  const int mt = tile / n_tiles, nt = tile - mt * n_tiles;
+  const int m0 = mt * DW2_BM, n0 = nt * DW2_BN;
+  const int kbeg = (int)((int64_t)split * a.k_per_split);
+  const int kend = (int)((kbeg + a.k_per_split < a.K) ? kbeg + a.k_per_split : a.K);
+  const int Ktot = (int)a.K;
+
+  const bool isB = tid >= 256;
+  const int t8 = tid & 255;
+  const int c4 = t8 & 63;   // columns 4 c4 .. 4 c4 + 3 of the tile
+  const int kb = t8 >> 6;   // rows 4 kb .. 4 kb + 3 of the K tile
+  const float* base = isB ? a.W[0] : a.A;
+  const int64_t ld = isB ? a.ldw : a.lda;
+  const int col = (isB ? n0 : m0) + 4 * c4;
+  const bool col_ok = col < (isB ? a.Nseg : (int)a.M);
+  const int32_t* ids = isB ? a.b_gather_ids : a.gather_ids;
+  const int gS = isB ? a.b_gather_S : a.gather_S;
+  float* sdst = (isB ? &Bs[0][0] : &As[0][0]);
+  int soff[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) soff[e] = dw_lds_off(4 * c4 + e, kb);
+  const bool do_cs = a.colsum != nullptr && nt == 0 && !isB;
+  f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+  f32x4 R[4];
+  int idr[4];
+  auto fetch_ids = [&](int k0) {
+    if constexpr (KG != 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int k = k0 + 4 * kb + e;
+        if (k > Ktot - 1) k = Ktot - 1;
+        if (KG == 1) idr[e] = ids[k];
+        else if (ids) {
+          const int n = k / gS;
+          idr[e] = ids[n] * gS + (k - n * gS);
+        } else idr[e] = k;
+      }
+    }
+  };
+  auto gload = [&](int k0, int e) {
+    const int k = k0 + 4 * kb + e;
+    const int64_t row = KG != 0 ? idr[e] : k;
+    const float* p = (col_ok && k < kend) ? base + row * ld + col : g_dw_zero;
+    R[e] = *reinterpret_cast<const f32x4*>(p);
+  };
+  auto sstore = [&](int buf, int e, bool fresh) {
+    const f32x4 v = {R[0][e], R[1][e], R[2][e], R[3][e]};
+    *reinterpret_cast<f32x4*>(sdst + buf * (DW2_BM * DW_BK) + soff[e]) = v;
+    if (do_cs && fresh) cs += R[e];
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int frow = lane & 31, fc = lane >> 5;
+  const int a_row0 = wm * 128 + frow, b_row0 = wn * 64 + frow;
+  f32x4 fa[4], fb[2];
+  int fao[4], fbo[2];  // k group 0 of each block row; k group 1: ^ 8 (the chunk index is XORed, and 2 kq + fc = 2 kq ^ fc)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fao[i] = dw_lds_off(a_row0 + 32 * i, fc);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) fbo[j] = dw_lds_off(b_row0 + 32 * j, fc);
+  auto ldfrag = [&](int buf, int kq) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const f32x4*>(&As[buf][fao[i] ^ (8 * kq)]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const f32x4*>(&Bs[buf][fbo[j] ^ (8 * kq)]);
+  };
+
+  const int nk = (kend - kbeg + DW_BK - 1) / DW_BK;
+  const int last = nk - 1;
+  auto ktile = [&](int t) { return kbeg + (t < last ? t : last) * DW_BK; };
+  if (nk > 0) {
+    fetch_ids(ktile(0));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gload(ktile(0), e);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sstore(0, e, true);
+    fetch_ids(ktile(1));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gload(ktile(1), e);
+  }
+  __syncthreads();
+  for (int t = 0; t < nk; ++t) {
+    const int buf = t & 1;
+    const int k2 = ktile(t + 2);
+    ldfrag(buf, 0);
+#pragma unroll
+    for (int kq = 0; kq < 2; ++kq) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int slot = kq * 4 + e;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+        if (slot == 3) ldfrag(buf, 1);  // one fragment set: behind the k group's last MFMAs
+        if (slot < 4) sstore(buf ^ 1, slot, t < last);
+        else gload(k2, slot - 4);
+        if (slot == 0) fetch_ids(k2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+  }
+
+  if (a.colsum != nullptr && nt == 0) {  // workgroup-uniform: the four threads (kb) that staged the same 4 columns add up
+    f32x4* red = reinterpret_cast<f32x4*>(&As[0][0]);
+    if (!isB) red[kb * 64 + c4] = cs;
+    __syncthreads();
+    if (!isB && kb == 0) {
+      const f32x4 v = (red[c4] + red[64 + c4]) + (red[128 + c4] + red[192 + c4]);
+      float* dst = a.colsum + (int64_t)split * a.M + m0 + 4 * c4;
+      if (col_ok) *reinterpret_cast<f32x4*>(dst) = v;
+    }
+  }
+
+  const int ccol = lane & 31, crow = 4 * (lane >> 5);
+  float* Cout = nsplit > 1 ? a.slabs + (int64_t)split * a.slab_stride : a.C;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int colj = n0 + wn * 64 + 32 * j + ccol;
+    if (colj >= a.Nseg) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t row = m0 + wm * 128 + 32 * i + (e & 3) + 8 * (e >> 2) + crow;
+        if (row < a.M) Cout[row * a.ldc + colj] = acc[i][j][e];
+      }
+  }
+}
+
 }  // namespace
 
 // Does this kernel serve the launch?  (dW layout, 16-byte aligned operands whose widths are multiples of 4, enough
@@ -215,7 +379,7 @@ __global__ __launch_bounds__(256, 3) void gemm_dw_kernel(GemmArgs a, int n_tiles
 // 768 x 768 x 96 000) and are 5 % slower here -- so by default (XNRS_GEMM_DW=1) only the live-row launches come here;
 // XNRS_GEMM_DW=2 sends every eligible launch (tests), 0 none.
 bool gemm_dw_eligible(const GemmArgs& a) {
-  if (knobs().gemm_dw < 2 && !a.gather_ids) return false;
+  if (!a.gather_ids && !(knobs().gemm_dw >= 3 || (knobs().gemm_dw == 2 && gemm_dw_big_tile(a)))) return false;
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   if (!a.a_col || !a.b_kn || a.nseg != 1 || a.accumulate || a.aux_mode || a.act || a.bias[0]) return false;
   if (a.M % 4 != 0 || a.Nseg % 4 != 0 || a.lda % 4 != 0 || a.ldw % 4 != 0 || !al16(a.A) || !al16(a.W[0])) return false;
@@ -227,7 +391,23 @@ bool gemm_dw_eligible(const GemmArgs& a) {
   return true;
 }
 
+// 256 x 256 tiles (gemm_dw256_kernel) for outputs of at least 1.5 x 1.5 tiles (XNRS_GEMM_DW_TILE=128 forces the small tile)
+bool gemm_dw_big_tile(const GemmArgs& a) { return knobs().gemm_dw_tile != 128 && a.M >= 384 && a.Nseg >= 384; }
+
 hipError_t launch_gemm_dw(const GemmArgs& a, int nsplit, hipStream_t stream) {
+  if (gemm_dw_big_tile(a)) {
+    const int64_t m_tiles = (a.M + DW2_BM - 1) / DW2_BM, n_tiles = (a.Nseg + DW2_BN - 1) / DW2_BN;
+    if (m_tiles * n_tiles * nsplit > 0x3fffffffLL) return hipErrorInvalidValue;
+    const int tiles = (int)(m_tiles * n_tiles);
+    const dim3 g((unsigned)(tiles * nsplit));
+    const bool none = !a.gather_ids && !a.b_gather_ids;
+    const bool live = a.gather_ids && a.b_gather_ids && a.gather_S == 1 && a.b_gather_S == 1;
+    if (none) hipLaunchKernelGGL((gemm_dw256_kernel<0>), g, dim3(512), 0, stream, a, (int)n_tiles, tiles, nsplit);
+    else if (live) hipLaunchKernelGGL((gemm_dw256_kernel<1>), g, dim3(512), 0, stream, a, (int)n_tiles, tiles, nsplit);
+    else if (!a.gather_ids) hipLaunchKernelGGL((gemm_dw256_kernel<2>), g, dim3(512), 0, stream, a, (int)n_tiles, tiles, nsplit);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
   const int64_t m_tiles = (a.M + DW_BM - 1) / DW_BM, n_tiles = (a.Nseg + DW_BN - 1) / DW_BN;
   if (m_tiles * n_tiles * nsplit > 0x3fffffffLL) return hipErrorInvalidValue;
   const int tiles = (int)(m_tiles * n_tiles);

@@ -777,10 +777,15 @@ size_t gemm_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K) {
 }
 
 int gemm_pick_splits(int64_t M, int64_t N, int64_t K, bool dw_kernel) {
-  // aim for one round of 128x128 workgroups (2 per CU x 256 CUs for the k-major variants, 3 per CU for gemm_dw.hip)
-  // and at least 256 contraction steps per slice
-  const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
-  int64_t ns = (dw_kernel ? 768 : 512) / tiles;
+  // aim for one round of 128x128 workgroups (2 per CU x 256 CUs for the k-major variants, 3 per CU for gemm_dw.hip; one
+  // 256x256 workgroup per CU for its big tile) and at least 256 contraction steps per slice
+  int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  int64_t slots = dw_kernel ? 768 : 512;
+  if (dw_kernel && knobs().gemm_dw_tile != 128 && M >= 384 && N >= 384) {
+    tiles = ((M + 255) / 256) * ((N + 255) / 256);
+    slots = 256;
+  }
+  int64_t ns = slots / tiles;
   const int64_t max_by_k = K / 256;
   if (ns > max_by_k) ns = max_by_k;
   if (ns > 64) ns = 64;
@@ -805,7 +810,8 @@ static Knobs read_knobs() {
   k.mha_headwave = num("XNRS_MHA_HEADWAVE", 1) != 0;
   k.mha_pair = num("XNRS_MHA_PAIR", 1) != 0;
   k.mha_bwd_fused = num("XNRS_MHA_BWD_FUSED", 1) != 0;
-  k.gemm_dw = (int)num("XNRS_GEMM_DW", 1);
+  k.gemm_dw = (int)num("XNRS_GEMM_DW", 2);
+  k.gemm_dw_tile = (int)num("XNRS_GEMM_DW_TILE", 256);
   k.fold_out = (int)num("XNRS_FOLD_OUT", 1);
   k.fc1_rowdot = num("XNRS_FC1_ROWDOT", 1) != 0;
   k.fold_train = (int)num("XNRS_FOLD_TRAIN", 1);

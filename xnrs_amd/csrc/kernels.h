@@ -24,7 +24,9 @@ struct Knobs {
   bool fc1_rowdot = true;       // XNRS_FC1_ROWDOT=0: inference materialises tanh(fc1 x) and the pooling kernel takes the fc2 dot
   int fold_train = 1;           // XNRS_FOLD_TRAIN=0: the training forward / backward keep the per-token out-projection
   int fold_out = 1;             // XNRS_FOLD_OUT=0: inference keeps the per-token out-projection (api.hip "fold")
-  int gemm_dw = 1;              // XNRS_GEMM_DW: 1 = live-row weight gradients on gemm_dw.hip, 2 = every eligible one, 0 = none
+  int gemm_dw = 2;              // XNRS_GEMM_DW: weight gradients on gemm_dw.hip -- 0 none, 1 the live-row launches, 2 (default) those +
+                                // the dense ones that take its 256 x 256 tile, 3 every eligible launch (tests)
+  int gemm_dw_tile = 256;       // XNRS_GEMM_DW_TILE=128: never the 256 x 256 tile of gemm_dw.hip
   int mha_lds = -1;             // XNRS_MHA_LDS=0|1 force / forbid the LDS-staged attention kernel; -1 = by shape
   bool mha_pair = true;         // XNRS_MHA_PAIR=0: the first-generation LDS-staged attention kernel instead of mha_core_pair_kernel
   int mha_headwave = 1;         // XNRS_MHA_HEADWAVE=0: generic attention kernel only
@@ -107,6 +109,7 @@ hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t stream, int* nsplit_us
 // dW = dY^T . X with the transpose done in registers on the way to LDS (gemm_dw.hip); nsplit / k_per_split / slab_stride
 // as filled in by launch_gemm_f32
 bool gemm_dw_eligible(const GemmArgs& a);
+bool gemm_dw_big_tile(const GemmArgs& a);  // would launch_gemm_dw take the 256 x 256 tile?
 hipError_t launch_gemm_dw(const GemmArgs& a, int nsplit, hipStream_t stream);
 // forward-layout GEMM on the bf16 matrix cores by operand splitting (gemm_split.hip); npl = 3 or 2 planes
 hipError_t launch_gemm_split(const GemmArgs& a, int npl, hipStream_t stream);
