@@ -273,11 +273,13 @@ def news_only_extra(device, steps=20, warmup=10):
             fn()
             torch.cuda.synchronize()
         dt = timed(fn, steps, warmup, False) / steps
-        # executed FLOPs: the <= 32-token shapes run the single fused kernel (full out-projection in the kernel), the
-        # 50 x 768 shape the pipeline with the out-projection folded behind the pooling
-        fl = 1024 * news_flops(S, D, 256, w["E"], folded=fold_on() and S > 32)
+        # EXECUTED FLOPs: the out-projection is folded behind the pooling on every path (the <= 32-token shapes inside the
+        # single fused kernel, the 50 x 768 shape on the pipeline): one D x D product per news instead of one per token
+        fl = 1024 * news_flops(S, D, 256, w["E"], folded=fold_on())
+        fl_ref = 1024 * news_flops(S, D, 256, w["E"])
         out[name] = dict(news_per_s=1024 / dt, ms=dt * 1e3, tflops=fl / dt / 1e12,
                          frac_fp32_mfma=fl / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                         reference_order_tflops=fl_ref / dt / 1e12,  # the same news at the reference's operation order: not a utilisation
                          alg_gbs=1024 * (4 * S * D + 4 * S + 4 * w["E"] + 4) / dt / 1e9)
     return out
 

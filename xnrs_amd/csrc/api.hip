@@ -34,7 +34,7 @@ struct Plan {
   size_t off_qkv, off_o, off_y, off_t, off_p, off_h;
   size_t off_stats, off_a;  // training only: softmax row statistics, pooling weights
   size_t off_planes;        // bf16-split GEMM modes: pre-split weight planes (wq, wk, wv, wo, w1)
-  size_t off_nf;            // fused short-sequence encoder: fragment-ordered weight images
+  size_t off_nf, off_nfo;   // fused short-sequence encoder: fragment-ordered weight images, O-row scratch (fold)
   size_t off_fw, off_fb, off_po, off_as, off_fsl;  // folded out-projection: W1.Wo, W1.bo + b1, pooled O rows, sum of weights, split-K slabs
   size_t total;
 };
@@ -79,6 +79,7 @@ Plan make_plan(int64_t n_seq, int L, int D, int A, int E, bool att, bool additiv
     else if (news_fused_plan(L, D, n_heads, A, &nf)) nfb = nf.img_bytes;
   }
   p.off_nf = nfb ? take((nfb + 3) / 4) : 0;
+  p.off_nfo = nfb ? take(news_fused_scratch_bytes(L, D) / 4) : 0;  // its O rows while the out-projection is folded away
   // folded out-projection (seq_encode "fold"): reserved whenever the shape is eligible, whatever the knob says
   const bool foldable = att && additive;  // (training keeps W', b', the pooled O rows and the weight sums for the backward)
   p.off_fw = foldable ? take((size_t)A * D) : 0;
@@ -266,7 +267,7 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
   bool fused = att && additive && !train && !a_out && att->dropout_p == 0.f && gemm_mode() == 0 &&
                knobs().news_fused && news_fused_plan(L, D, att->n_heads, A, nullptr) &&
                (D / att->n_heads) * att->n_heads == D &&
-               (knobs().news_fused == 2 || (L >= 26 && n_seq >= 192 && n_seq < 1536));
+               (knobs().news_fused == 2 || (L >= 26 && n_seq >= 192));
   if (fused) {
     f.x = x; f.ids = ids; f.mask = m;
     f.wq = att->wq; f.bq = att->bq; f.wk = att->wk; f.bk = att->bk; f.wv = att->wv; f.bv = att->bv;
@@ -279,9 +280,15 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
     f.n_seq = n_seq;
     f.S = L; f.D = D; f.n_heads = att->n_heads; f.d_k = D / att->n_heads; f.A = A; f.scaled = att->scaled;
     f.npw = knobs().news_fused_npw ? knobs().news_fused_npw : (n_seq < 512 ? 1 : 2);
+    if (fold_wanted(knobs().fold_out)) {  // the kernel pools the attention rows; Wo is applied once per news below
+      f.fold = 1;
+      f.o_scratch = reinterpret_cast<float*>(w + p.off_nfo);
+      f.asum = reinterpret_cast<float*>(w + p.off_as);
+      f.p = reinterpret_cast<float*>(w + p.off_po);
+    }
     fused = p.off_nf != 0 && news_fused_ready(f);
   }
-  const bool fold = att && additive && !fused && fold_wanted(train ? knobs().fold_train : knobs().fold_out);
+  const bool fold = att && additive && fold_wanted(train ? knobs().fold_train : knobs().fold_out);
   float* wf = reinterpret_cast<float*>(w + p.off_fw);
   float* bf = reinterpret_cast<float*>(w + p.off_fb);
   float* pob = reinterpret_cast<float*>(w + p.off_po);
@@ -298,6 +305,10 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
     fc1_b = fold_out_projection(att, pool, D, A, wf, bf, reinterpret_cast<float*>(w + p.off_fsl), stream, &fe);
     XNRS_TRY(fe);
     fc1_w = wf;
+    if (fused) {  // the fused kernel's fc1 image is built from the folded pair
+      f.w1 = fc1_w;
+      f.b1 = fc1_b;
+    }
   }
 
   // Additive-only towers (no self-attention: StandardRec / BaseRec / NAML / LSTUR news encoders) from a batch that fills
@@ -356,7 +367,7 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
   // 28 160 x 30: 8.2 vs 7.1 ms; 64 x 30: 111 vs 104 us, 1024 x 20: 318 vs 255 us.  XNRS_NEWS_FUSED=2 forces the kernel
   // for every eligible shape (tests), 0 turns it off.
   if (fused) {
-    const double fl = (double)n_seq * (8.0 * L * D * D + 4.0 * L * L * D + 2.0 * L * D * A + 2.0 * L * (A + D));
+    const double fl = (double)n_seq * ((f.fold ? 6.0 : 8.0) * L * D * D + 4.0 * L * L * D + 2.0 * L * D * A + 2.0 * L * (A + D));
     ProfScope ps(6, fl, stream);
     XNRS_TRY(launch_news_fused(f, stream));
   }

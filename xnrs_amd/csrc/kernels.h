@@ -278,6 +278,13 @@ struct NewsFusedArgs {
   int32_t S, D, n_heads, d_k, A, scaled;
   int32_t npw;         // news per workgroup: 2 (default, 0 means 2) or 1
   int32_t tanh_act;    // filled in by the launcher: 2 = ocml tanhf, 3 = fast_tanh (knob)
+  // fold (api.hip "fold": the out-projection behind the pooling): w1 / b1 are then the FOLDED fc1 (W1.Wo, W1.bo + b1), the
+  // kernel skips the out-projection, pools the attention rows O and emits p = sum_i a_i O_i and asum = sum_i a_i; the
+  // caller applies Wo once per news.  o_scratch: news_fused_scratch_bytes() of L2-resident scratch (the O tiles of a
+  // workgroup's news are parked there while the token rows still occupy LDS).
+  int32_t fold;
+  float* o_scratch;
+  float* asum;         // [n_seq] (fold only)
 };
 struct NewsFusedPlan {
   int npw, hg, lq, ly;  // news per workgroup, heads per group, LDS row strides of the Q|K|V and Y images
@@ -288,6 +295,7 @@ struct NewsFusedPlan {
 // does the fused kernel cover this shape (and with which plan)?
 bool news_fused_plan(int S, int D, int n_heads, int A, NewsFusedPlan* plan, int npw = 2);
 size_t news_fused_img_bound_bytes(int S, int D, int A);  // >= img_bytes for every n_heads; 0: no head count is eligible
+size_t news_fused_scratch_bytes(int S, int D);            // NewsFusedArgs::o_scratch (fold), whatever the batch size
 // the launch's remaining preconditions (16-byte aligned operands, 160 KB of dynamic LDS granted on the CURRENT device);
 // false = use the GEMM pipeline for this call
 bool news_fused_ready(const NewsFusedArgs& a);

@@ -213,9 +213,13 @@ constexpr int NF_NSTAMP = 32;
     mma(IC<0>{}, IC<3>{});                                          \
   }
 
-template <int DK4, int NPW>
+// FOLD: the out-projection is applied by the caller once per news (NewsFusedArgs::fold): no Y accumulators, no
+// out-projection loops (16 % of the workgroup's time at D = 320), the attention rows O of every head group go to the
+// workgroup's slot of an L2-resident scratch and come back into R1 once the token rows are dead.
+// PERSISTENT: a workgroup walks news groups blockIdx.x, + gridDim.x, ... (its scratch slot is its own for the launch).
+template <int DK4, int NPW, bool FOLD>
 __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kernel(NewsFusedArgs a, NfImg im, const float* __restrict__ img, int HG,
-                                                                   int LQ, int LY) {
+                                                                   int LQ, int LY, int64_t n_wg) {
   constexpr int TR = 2 * NPW, TRC = NPW;  // 16-row tiles per workgroup (32 virtual rows per news); per wave in (c)
   constexpr int TF = NF_TF, TY = NF_TY, TA = NF_TA;
   constexpr int dk = 4 * DK4;  // head width: compile-time, so the attention core is one straight run of MFMAs
@@ -231,7 +235,9 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wf = wave & 3, wr = wave >> 2;  // out-projection: feature quarter, row half (NPW = 2: news wr)
   const int c = lane & 15, g = lane >> 4;
-  const int64_t news0 = (int64_t)blockIdx.x * NPW;
+  float* const osc = FOLD ? a.o_scratch + (size_t)blockIdx.x * nrow * D : nullptr;  // this workgroup's O rows [nrow][D]
+  for (int64_t wgi = blockIdx.x; wgi < n_wg; wgi += gridDim.x) {
+  const int64_t news0 = wgi * NPW;
 
   // ---- token rows -> R1, coalesced 16-byte chunks.  A news past the end of the batch is a duplicate of the last one
   // (computed, never stored), so no uninitialised LDS is ever read.
@@ -454,17 +460,22 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
 #pragma unroll
               for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[kt][dt][r], sc[qt][kt][r], o, 0, 0, 0);
             const int query = 16 * qt + c, dv0 = 16 * dt + 4 * g;
-            if (query < S && dv0 < dk) *reinterpret_cast<f32x4*>(Qb + query * LQ + dv0) = o;
+            if (query < S && dv0 < dk) {
+              if (FOLD) *reinterpret_cast<f32x4*>(osc + (size_t)(nw * S + query) * D + (h0 + hh) * dk + dv0) = o;
+              else *reinterpret_cast<f32x4*>(Qb + query * LQ + dv0) = o;
+            }
           }
       }
     }
     NF_STAMP(5 + 6 * (grp & 3));
-    __syncthreads();
+    // (FOLD: no out-projection reads R2 here, and the next group's projection epilogue waits at its own barrier before
+    // it overwrites R2 -- a wave that is done with its heads walks straight into the next k loop)
+    if (!FOLD) __syncthreads();
     NF_STAMP(6 + 6 * (grp & 3));
 
     // ================= (c) out-projection, this group's columns of Wo: Y^T[d][row] += Wo[d][h0 d_k + k] O[row][k]
     // wave (wf, wr): feature tiles wf + 4 t, the two row tiles of news wr
-    {
+    if constexpr (!FOLD) {
       const float* wc = imgl + im.off_wo(grp) + (size_t)wf * TY * NF_FRAG;
       const int nkc = (NW + 15) >> 4;
       f32x4 fa[2][TY], fb[2][TRC];
@@ -493,16 +504,24 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
   }
 
   // ================= Y = att output (+ bo) -> R1 [row][LY]  (X is dead: every group's projection has read it)
-  __syncthreads();
+  __syncthreads();  // (FOLD: also publishes the O rows every wave wrote to the scratch)
   NF_STAMP(26);
+  if constexpr (FOLD) {  // the attention rows O come back from the scratch (L2 hits: written a few microseconds ago)
+    const int cpr = D >> 2;
+    for (int i = tid; i < nrow * cpr; i += NF_THREADS) {
+      const int row = i / cpr, ch = i - row * cpr;
+      *reinterpret_cast<f32x4*>(&r1[row * LY + 4 * ch]) = *reinterpret_cast<const f32x4*>(osc + (size_t)row * D + 4 * ch);
+    }
+  } else {
 #pragma unroll
-  for (int t = 0; t < TY; ++t) {
-    const int d0 = 16 * (wf + 4 * t) + 4 * g;
-    if (d0 < D) {
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(img + im.off_bo() + (wf * TY + t) * 16 + 4 * g);
+    for (int t = 0; t < TY; ++t) {
+      const int d0 = 16 * (wf + 4 * t) + 4 * g;
+      if (d0 < D) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(img + im.off_bo() + (wf * TY + t) * 16 + 4 * g);
 #pragma unroll
-      for (int i = 0; i < TRC; ++i)
-        if (ok_c[i]) *reinterpret_cast<f32x4*>(&r1[prow_c[i] * LY + d0]) = yacc[t][i] + bv;
+        for (int i = 0; i < TRC; ++i)
+          if (ok_c[i]) *reinterpret_cast<f32x4*>(&r1[prow_c[i] * LY + d0]) = yacc[t][i] + bv;
+      }
     }
   }
   __syncthreads();
@@ -587,6 +606,7 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
     float den = 0.f;
     for (int s = 0; s < S; ++s) den += aw[nw * 32 + s];
     aw[NPW * 32 + tid] = aw[tid] / (den + 1e-8f);
+    if (FOLD && (tid & 31) == 0 && news0 + nw < a.n_seq) a.asum[news0 + nw] = den / (den + 1e-8f);  // sum_i a_i
   }
   __syncthreads();
   const int d4n = D >> 2;
@@ -616,6 +636,8 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
     }
   }
   NF_STAMP(31);
+  __syncthreads();  // R1 / aw are rewritten by the next news group
+  }
 }
 
 int stride8(int n) {  // smallest stride >= n with stride % 16 == 8: conflict-free 16-byte fragment reads (16 rows x 4 chunks)
@@ -664,15 +686,15 @@ namespace {
 // DEVICE (hipFuncSetAttribute acts on the current device's code object): the result is cached per (device, instantiation).
 constexpr int NF_MAX_DEV = 64;
 std::mutex g_attr_mu;
-signed char g_attr_state[NF_MAX_DEV][8][2];  // 0 unknown, 1 ok, -1 refused (e.g. a part with less than 160 KB of LDS)
+signed char g_attr_state[NF_MAX_DEV][8][2][2];  // 0 unknown, 1 ok, -1 refused (e.g. a part with less than 160 KB of LDS)
 
-template <int Q, int N>
+template <int Q, int N, bool F>
 bool nf_attr_ok(int dev) {
   if (dev < 0 || dev >= NF_MAX_DEV) return false;
   std::lock_guard<std::mutex> lk(g_attr_mu);
-  signed char& st = g_attr_state[dev][Q - 1][N - 1];
+  signed char& st = g_attr_state[dev][Q - 1][N - 1][F ? 1 : 0];
   if (st == 0) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&news_fused_kernel<Q, N>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&news_fused_kernel<Q, N, F>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) (void)hipGetLastError();  // a refusal is an answer, not a sticky error of the caller's stream
     st = e == hipSuccess ? 1 : -1;
@@ -680,9 +702,11 @@ bool nf_attr_ok(int dev) {
   return st == 1;
 }
 
-bool nf_attr_ok(int q, int npw, int dev) {
+bool nf_attr_ok(int q, int npw, bool fold, int dev) {
 #define NF_A(Q) \
-  case Q: return npw == 1 ? nf_attr_ok<Q, 1>(dev) : nf_attr_ok<Q, 2>(dev);
+  case Q:       \
+    return npw == 1 ? (fold ? nf_attr_ok<Q, 1, true>(dev) : nf_attr_ok<Q, 1, false>(dev)) \
+                    : (fold ? nf_attr_ok<Q, 2, true>(dev) : nf_attr_ok<Q, 2, false>(dev));
   switch (q) {
     NF_A(1) NF_A(2) NF_A(3) NF_A(4) NF_A(5) NF_A(6) NF_A(7) NF_A(8)
     default: return false;
@@ -701,10 +725,32 @@ bool news_fused_ready(const NewsFusedArgs& a) {
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   if (!al16(a.x) || !al16(a.wq) || !al16(a.wk) || !al16(a.wv) || !al16(a.wo) || !al16(a.w1) || !a.img || !al16(a.img))
     return false;
+  if (a.fold && (!a.o_scratch || !a.asum || !al16(a.o_scratch))) return false;
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess) return false;
-  return nf_attr_ok(a.d_k / 4, npw, dev);
+  return nf_attr_ok(a.d_k / 4, npw, a.fold != 0, dev);
 }
+
+// persistent grid: one workgroup per CU with 2 news each, two per CU with 1 news each (NewsFusedPlan); the scratch holds
+// every workgroup's O rows: <= 512 x 32 x 320 floats = 21 MB, written and read back within a news group's ~80 us
+namespace {
+int nf_cu_count() {
+  static std::mutex mu;
+  static int cus[NF_MAX_DEV] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NF_MAX_DEV) return 256;
+  std::lock_guard<std::mutex> lk(mu);
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+constexpr int NF_MAX_GRID = 1024;  // scratch slots reserved (2 workgroups x 512 CUs at most)
+}  // namespace
+
+size_t news_fused_scratch_bytes(int S, int D) { return (size_t)NF_MAX_GRID * (size_t)S * (size_t)D * sizeof(float); }
 
 hipError_t launch_news_fused(const NewsFusedArgs& a_in, hipStream_t stream) {
   NewsFusedArgs a = a_in;
@@ -719,20 +765,30 @@ hipError_t launch_news_fused(const NewsFusedArgs& a_in, hipStream_t stream) {
   hipLaunchKernelGGL(news_fused_prep_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, a, im, p.hg, a.img);
   hipError_t pe = hipGetLastError();
   if (pe != hipSuccess) return pe;
-  const int64_t grid = (a.n_seq + p.npw - 1) / p.npw;
-  if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  const int64_t n_wg = (a.n_seq + p.npw - 1) / p.npw;
+  int64_t grid = (int64_t)nf_cu_count() * (npw == 1 ? 2 : 1);  // persistent: what is co-resident
+  if (grid > NF_MAX_GRID / npw) grid = NF_MAX_GRID / npw;       // (a workgroup's scratch slot is npw * S * D floats)
+  if (grid > n_wg) grid = n_wg;
   hipError_t rc = hipErrorInvalidValue;
-#define NF_LAUNCH(Q, N)                                                                                                    \
-  hipLaunchKernelGGL((news_fused_kernel<Q, N>), dim3((unsigned)grid), dim3(NF_THREADS), p.lds_bytes, stream, a, im, a.img, \
-                     p.hg, p.lq, p.ly);                                                                                    \
+#define NF_LAUNCH(Q, N, F)                                                                                                    \
+  hipLaunchKernelGGL((news_fused_kernel<Q, N, F>), dim3((unsigned)grid), dim3(NF_THREADS), p.lds_bytes, stream, a, im, a.img, \
+                     p.hg, p.lq, p.ly, n_wg);                                                                                 \
   rc = hipGetLastError();
-#define NF_CASE(Q)             \
-  case Q:                      \
-    if (npw == 1) {            \
-      NF_LAUNCH(Q, 1)          \
-    } else {                   \
-      NF_LAUNCH(Q, 2)          \
-    }                          \
+#define NF_CASE(Q)                  \
+  case Q:                           \
+    if (npw == 1) {                 \
+      if (a.fold) {                 \
+        NF_LAUNCH(Q, 1, true)       \
+      } else {                      \
+        NF_LAUNCH(Q, 1, false)      \
+      }                             \
+    } else {                        \
+      if (a.fold) {                 \
+        NF_LAUNCH(Q, 2, true)       \
+      } else {                      \
+        NF_LAUNCH(Q, 2, false)      \
+      }                             \
+    }                               \
     break;
   switch (a.d_k / 4) {
     NF_CASE(1) NF_CASE(2) NF_CASE(3) NF_CASE(4) NF_CASE(5) NF_CASE(6) NF_CASE(7) NF_CASE(8)
