@@ -58,10 +58,16 @@ typedef struct {
   uint64_t seed;    /* counter-based RNG seed for dropout; ignored when dropout_p == 0 */
 } xnrs_mha_params;
 
-/* layers.AdditiveAttention parameters (layers.py:42-45): fc1 Linear(D,A), fc2 Linear(A,1) */
+/* layers.AdditiveAttention parameters (layers.py:42-45): fc1 Linear(D,A), fc2 Linear(A,1).
+ * w1_folded / b1_folded (optional, inference entry points only; ABI version 3): fc1 folded behind the out-projection of
+ * the attention stage passed IN THE SAME CALL -- W1.Wo [A,D] and W1.bo + b1 [A], as xnrs_fold_weights computes them
+ * (DESIGN.md section 4.6).  The library keeps no state between calls, so without them every call rebuilds the pair
+ * (three short launches, ~20 us); a caller that encodes with the same weights again and again computes them once
+ * (xnrs_amd/hip.py caches them per module and weight version).  NULL = rebuilt per call; the bits are the same. */
 typedef struct {
   const float *w1, *b1, *w2, *b2;
   int32_t hidden; /* A */
+  const float *w1_folded, *b1_folded;
 } xnrs_additive_params;
 
 /* nn.Sequential(Linear(in,out), activation, Linear(out,out)) head
@@ -120,6 +126,13 @@ int32_t xnrs_text_encoder_fwd(const float *x, const float *m, const int32_t *ids
                               int32_t S, int32_t D, const xnrs_mha_params *att, int32_t pool_kind,
                               const xnrs_additive_params *pool, const xnrs_head_params *head, float *y,
                               float *hm, int64_t chunk, void *ws, size_t ws_bytes, void *stream);
+
+/* The folded fc1 of an (attention stage, additive pooler) pair, for xnrs_additive_params.w1_folded / b1_folded:
+ *   w1f [A, D] = W1 . Wo      b1f [A] = W1 . bo + b1      (layers.py:154 behind layers.py:60, exact algebra)
+ * ws: xnrs_fold_weights_workspace_bytes(D, A) of scratch. */
+size_t xnrs_fold_weights_workspace_bytes(int32_t D, int32_t A);
+int32_t xnrs_fold_weights(const xnrs_mha_params *att, const xnrs_additive_params *pool, int32_t D, float *w1f, float *b1f,
+                          void *ws, size_t ws_bytes, void *stream);
 
 /* ---- TextEncoder.forward without the padding work (inference) --------------------------------
  * Same result as xnrs_text_encoder_fwd for 0/1 masks, computing only what can reach the output

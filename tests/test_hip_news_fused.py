@@ -175,3 +175,33 @@ def test_fold_inside_the_fused_kernel_and_dispatch_threshold():
             hip.profile_enable(0)
             assert (st["news_fused"][1] == 1) == fused and (st["qkv_gemm"][1] == 0) == fused, (n, st)
             H.assert_close(y, y_fold[:, :n], 2e-5, f"news vectors across the dispatch switch (n = {n})")
+
+
+@pytest.mark.parametrize("shape", [(30, 320, 16), (50, 768, 16)], ids=["fused_kernel_shape", "pipeline_shape"])
+def test_fold_cache_is_bitwise_neutral_and_follows_weight_updates(shape):
+    """xnrs_additive_params.w1_folded / b1_folded from the caller-side cache (xnrs_amd/hip.py: folded_fc1, built once per
+    weight version by xnrs_fold_weights) against the per-call rebuild: the same bits; an in-place weight update (what an
+    optimizer step or load_state_dict does) invalidates the cached pair."""
+    S, D, h = shape
+    enc, _ = build(S, D, h, 64, 4242)
+    x, m = synth.token_block(synth.rng_for(4243), 1, 300, S, D, min_len=1, full_pad_prob=0.1)
+    x, m = x.to(DEV), m.to(DEV)
+    with torch.no_grad():
+        y_cached, _ = enc((x, m))
+        key = (id(enc.att), id(enc.pooler))
+        assert key in hip._fold_cache
+        y_again, _ = enc((x, m))
+        hip.FOLD_CACHE = False
+        try:
+            y_plain, _ = enc((x, m))
+        finally:
+            hip.FOLD_CACHE = True
+        assert torch.equal(y_cached, y_plain) and torch.equal(y_again, y_cached)
+        enc.att.out.weight.mul_(1.25)  # in-place: _version moves, storage stays
+        y_new, _ = enc((x, m))
+        hip.FOLD_CACHE = False
+        try:
+            y_new_plain, _ = enc((x, m))
+        finally:
+            hip.FOLD_CACHE = True
+        assert torch.equal(y_new, y_new_plain) and not torch.equal(y_new, y_cached)

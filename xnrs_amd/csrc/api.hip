@@ -210,6 +210,21 @@ const float* fold_out_projection(const xnrs_mha_params* att, const xnrs_additive
   return bf;
 }
 
+// dst[n] = Wo po[n] + bo s[n]: the out-projection behind the pooling.  fp32 GEMM mode: the bias term rides in the GEMM's
+// epilogue (fmaf(s, bo, acc): the same bits as the separate pass, one launch less); split modes keep the separate pass.
+hipError_t pooled_out_projection(const float* po, const float* s, const xnrs_mha_params* att, float* dst, int64_t n, int D,
+                                 const unsigned short* planes, hipStream_t stream) {
+  GemmArgs g = gemm1(po, nullptr, 0, D, att->wo, nullptr, dst, D, n, D, D, XNRS_ACT_NONE, planes);
+  const bool in_epilogue = att->bo && gemm_mode() == 0;
+  if (in_epilogue) {
+    g.rowscale = s;
+    g.rowscale_vec = att->bo;
+  }
+  hipError_t e = launch_gemm_f32(g, stream);
+  if (e != hipSuccess || !att->bo || in_epilogue) return e;
+  return launch_add_rowscaled_bias(dst, D, s, att->bo, n, D, stream);
+}
+
 // x:(n_seq,L,D) [or table + ids], m:(n_seq,L) [or table mask] -> y
 //   pooled == false: y:(n_seq,L,D) = att(x)            (MultiHeadAttention alone)
 //   pooled == true : y:(n_seq,E')  = head(pool(att(x)))
@@ -301,10 +316,16 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
   const float* fc1_w = additive ? pool->w1 : nullptr;
   const float* fc1_b = additive ? pool->b1 : nullptr;
   if (fold) {
-    hipError_t fe = hipSuccess;
-    fc1_b = fold_out_projection(att, pool, D, A, wf, bf, reinterpret_cast<float*>(w + p.off_fsl), stream, &fe);
-    XNRS_TRY(fe);
-    fc1_w = wf;
+    if (!train && pool->w1_folded) {  // the caller's copy of the folded pair (xnrs_fold_weights): nothing to rebuild
+      fc1_w = pool->w1_folded;
+      fc1_b = att->bo ? pool->b1_folded : pool->b1;
+      if (att->bo && !pool->b1_folded) return XNRS_EINVAL;
+    } else {
+      hipError_t fe = hipSuccess;
+      fc1_b = fold_out_projection(att, pool, D, A, wf, bf, reinterpret_cast<float*>(w + p.off_fsl), stream, &fe);
+      XNRS_TRY(fe);
+      fc1_w = wf;
+    }
     if (fused) {  // the fused kernel's fc1 image is built from the folded pair
       f.w1 = fc1_w;
       f.b1 = fc1_b;
@@ -531,11 +552,10 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
       }
     }
   }
-  if (fold) {  // pooled = Wo (sum_i a_i O_i) + bo (sum_i a_i): one out-projection per sequence
+  if (fold) {  // pooled = Wo (sum_i a_i O_i) + bo (sum_i a_i): one out-projection per sequence, the bias term in its epilogue
     float* dst = head ? pb : y;
     ProfScope ps(2, 2.0 * n_seq * (double)D * D, stream);
-    XNRS_TRY(launch_gemm_f32(gemm1(pob, nullptr, 0, D, att->wo, nullptr, dst, D, n_seq, D, D, XNRS_ACT_NONE, po), stream));
-    if (att->bo) XNRS_TRY(launch_add_rowscaled_bias(dst, D, asum, att->bo, n_seq, D, stream));
+    XNRS_TRY(pooled_out_projection(pob, asum, att, dst, n_seq, D, po, stream));
   }
   if (pooled && head) {
     ProfScope ps(5, 2.0 * n_seq * ((double)D * E + (double)E * E), stream);
@@ -691,10 +711,16 @@ int32_t xnrs_text_encoder_fwd_unpadded(const float* x, const int32_t* ids, int64
   const float* fc1_w = pool->w1;
   const float* fc1_b = pool->b1;
   if (fold) {
-    hipError_t fe = hipSuccess;
-    fc1_b = fold_out_projection(att, pool, D, A, wf, bf, reinterpret_cast<float*>(w + p.off_fsl), stream, &fe);
-    XNRS_TRY(fe);
-    fc1_w = wf;
+    if (pool->w1_folded) {
+      fc1_w = pool->w1_folded;
+      fc1_b = att->bo ? pool->b1_folded : pool->b1;
+      if (att->bo && !pool->b1_folded) return XNRS_EINVAL;
+    } else {
+      hipError_t fe = hipSuccess;
+      fc1_b = fold_out_projection(att, pool, D, A, wf, bf, reinterpret_cast<float*>(w + p.off_fsl), stream, &fe);
+      XNRS_TRY(fe);
+      fc1_w = wf;
+    }
   }
   if (att) {
     const int dk = D / att->n_heads;
@@ -784,8 +810,7 @@ int32_t xnrs_text_encoder_fwd_unpadded(const float* x, const int32_t* ids, int64
   if (fold) {
     float* dst = head ? pb : y;
     ProfScope ps(2, 2.0 * n_news * (double)D * D, stream);
-    XNRS_TRY(launch_gemm_f32(gemm1(pob, nullptr, 0, D, att->wo, nullptr, dst, D, n_news, D, D, XNRS_ACT_NONE), stream));
-    if (att->bo) XNRS_TRY(launch_add_rowscaled_bias(dst, D, asum, att->bo, n_news, D, stream));
+    XNRS_TRY(pooled_out_projection(pob, asum, att, dst, n_news, D, nullptr, stream));
   }
   if (head) {
     ProfScope ps(5, 2.0 * n_news * ((double)D * E + (double)E * E), stream);
@@ -814,6 +839,24 @@ int32_t xnrs_set_gemm_mode(int32_t mode) {
 }
 
 int32_t xnrs_get_gemm_mode(void) { return xnrs::gemm_mode(); }
+
+size_t xnrs_fold_weights_workspace_bytes(int32_t D, int32_t A) {
+  return D > 0 && A > 0 ? align_up((size_t)FOLD_SPLITS * A * D * sizeof(float)) : 0;
+}
+
+int32_t xnrs_fold_weights(const xnrs_mha_params* att, const xnrs_additive_params* pool, int32_t D, float* w1f, float* b1f,
+                          void* ws, size_t ws_bytes, void* stream) {
+  if (!att || !pool || !att->wo || !pool->w1 || pool->hidden <= 0 || D <= 0 || !w1f || !b1f) return XNRS_EINVAL;
+  if (ws_bytes < xnrs_fold_weights_workspace_bytes(D, pool->hidden) || !ws) return XNRS_EWORKSPACE;
+  hipError_t fe = hipSuccess;
+  const float* b = fold_out_projection(att, pool, D, pool->hidden, w1f, b1f, static_cast<float*>(ws), (hipStream_t)stream, &fe);
+  XNRS_TRY(fe);
+  if (b != b1f) {  // no out-projection bias: b1 as it is (or zeros)
+    if (pool->b1) XNRS_TRY(hipMemcpyAsync(b1f, pool->b1, (size_t)pool->hidden * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    else XNRS_TRY(hipMemsetAsync(b1f, 0, (size_t)pool->hidden * sizeof(float), (hipStream_t)stream));
+  }
+  return XNRS_OK;
+}
 
 int32_t xnrs_train_fold_enabled(void) { return fold_wanted(knobs().fold_train) ? 1 : 0; }
 

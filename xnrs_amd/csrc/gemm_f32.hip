@@ -586,6 +586,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
           }
           float v = acc[i][j][e];
           if (!split) {
+            if (a.rowscale) v = fmaf(a.rowscale[row], a.rowscale_vec[col], v);
             v = apply_act(v + bv, a.act);
             if (a.aux_mode) {
               const float x = a.aux[row * a.ldaux + coff];
@@ -869,7 +870,9 @@ hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t stream, int* nsplit
   // the split kernel has one tile shape (128x128): below one full round of workgroups the fp32 kernel with its
   // smaller tiles is faster (measured: 4099 x 260 x 300 -> 38 TF fp32 vs 22 TF split)
   const int64_t min_tiles = knobs().split_min_tiles;  // tests force the split kernel onto tiny shapes with 0
-  if (mode && !a.rowdot_out && !a.a_col && !a.b_kn && vec && nsplit == 1 &&
+  if (a.rowscale && (a.a_col || a.b_kn || a.nseg != 1 || nsplit != 1 || !a.rowscale_vec || a.c_scatter || a.rowdot_out))
+    return hipErrorInvalidValue;  // rank-1 epilogue term: plain forward launches only
+  if (mode && !a.rowdot_out && !a.rowscale && !a.a_col && !a.b_kn && vec && nsplit == 1 &&
       ((a.M + 127) / 128) * ((a.Nseg + 127) / 128) * a.nseg >= min_tiles)
     return launch_gemm_split(a, mode == 1 ? 3 : 2, stream);
   if (!a.a_col && !a.b_kn) e = launch_layout<false, false>(a, vec, nsplit, stream);

@@ -92,6 +92,10 @@ struct GemmArgs {
   const float* rowdot_w;
   float* rowdot_out;
   int64_t ldrd;
+  // forward layout, one segment, no split-K (nullable pair): rank-1 term of the epilogue, C[m][n] = fmaf(rowscale[m],
+  // rowscale_vec[n], acc) before bias / activation (the out-projection bias behind a pooled out-projection: bo * sum_i a_i)
+  const float* rowscale;
+  const float* rowscale_vec;
   // split-K (deterministic slabs + ordered reduce); set by the caller via slabs/nsplit
   float* slabs;        // nullable workspace of nsplit * M * ldc floats
   int32_t nsplit;

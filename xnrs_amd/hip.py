@@ -32,6 +32,7 @@ SYMBOLS = (
     "xnrs_embedding_linear_bwd_workspace_bytes", "xnrs_embedding_linear_bwd", "xnrs_dot_scoring_bwd", "xnrs_dot_scoring_norm_bwd",
     "xnrs_assemble_train_batch", "xnrs_assemble_eval_batch", "xnrs_score_csr", "xnrs_rank_metrics", "xnrs_gather_rows",
     "xnrs_infonce_saved_bytes", "xnrs_infonce_fwd", "xnrs_infonce_bwd", "xnrs_train_fold_enabled",
+    "xnrs_fold_weights_workspace_bytes", "xnrs_fold_weights",
 )
 POOL_NONE = -1
 PROFILE_STAGES = ("qkv_gemm", "attention_core", "out_gemm", "fc1_tanh_gemm", "pool", "head_gemms", "news_fused",
@@ -49,7 +50,8 @@ class MhaParams(C.Structure):
 
 
 class AdditiveParams(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("w1", "b1", "w2", "b2")] + [("hidden", C.c_int32)]
+    _fields_ = [(n, C.c_void_p) for n in ("w1", "b1", "w2", "b2")] + [("hidden", C.c_int32)] + [
+        (n, C.c_void_p) for n in ("w1_folded", "b1_folded")]
 
 
 class HeadParams(C.Structure):
@@ -175,6 +177,10 @@ def lib():
     l.xnrs_profile_read.argtypes = [p, p, p]
     l.xnrs_train_fold_enabled.restype = i32
     l.xnrs_train_fold_enabled.argtypes = []
+    l.xnrs_fold_weights_workspace_bytes.restype = sz
+    l.xnrs_fold_weights_workspace_bytes.argtypes = [i32, i32]
+    l.xnrs_fold_weights.restype = i32
+    l.xnrs_fold_weights.argtypes = [C.POINTER(MhaParams), C.POINTER(AdditiveParams), i32, p, p, p, sz, p]
     if l.xnrs_abi_version() != 3:
         raise XnrsHipError("libxnrs_hip.so ABI version mismatch; rebuild it")
     _lib = l
@@ -300,9 +306,47 @@ def mha_params(att, dropout_p: float = 0.0, seed: int = 0):
     return p, ts
 
 
-def additive_params(pool):
+def additive_params(pool, att=None):
+    """att (optional, inference): the attention stage the pooler sits behind in this call -- the folded fc1 (W1.Wo,
+    W1.bo + b1; include/xnrs_hip.h: xnrs_additive_params.w1_folded) is then attached from a per-module cache instead of
+    being rebuilt by every call."""
     ts = [dev_f32(t, "additive weight") for t in (pool.fc1.weight, pool.fc1.bias, pool.fc2.weight, pool.fc2.bias)]
-    return AdditiveParams(*[t.data_ptr() for t in ts], pool.fc1.out_features), ts
+    p = AdditiveParams(*[t.data_ptr() for t in ts], pool.fc1.out_features, None, None)
+    if att is not None and FOLD_CACHE:
+        w1f, b1f = folded_fc1(att, pool)
+        p.w1_folded, p.b1_folded = w1f.data_ptr(), b1f.data_ptr()
+        ts = ts + [w1f, b1f]
+    return p, ts
+
+
+#: cache of folded fc1 weights per (attention module, pooler module): {key: (fingerprint, w1f, b1f)}.  The C ABI keeps no
+#: state between calls; this is the CALLER's cache it is designed for.  A weight update (optimizer step, load_state_dict:
+#: in-place, so the tensors' _version moves) or a move to another device (new storage) changes the fingerprint.
+FOLD_CACHE = os.environ.get("XNRS_FOLD_CACHE", "1") != "0"
+_fold_cache = {}
+
+
+def folded_fc1(att, pool):
+    src = (att.out.weight, att.out.bias, pool.fc1.weight, pool.fc1.bias)
+    fp = tuple((t.data_ptr(), t._version, str(t.device), t.dtype) for t in src)
+    key = (id(att), id(pool))
+    hit = _fold_cache.get(key)
+    if hit is not None and hit[0] == fp:
+        return hit[1], hit[2]
+    ap, keep_a = mha_params(att)
+    pp, keep_p = additive_params(pool)
+    dev = pool.fc1.weight.device
+    A, D = pool.fc1.out_features, pool.fc1.in_features
+    w1f = torch.empty((A, D), dtype=torch.float32, device=dev)
+    b1f = torch.empty((A,), dtype=torch.float32, device=dev)
+    l = lib()
+    nws = l.xnrs_fold_weights_workspace_bytes(D, A)
+    ws = workspace(dev, nws)
+    check(l.xnrs_fold_weights(C.byref(ap), C.byref(pp), D, ptr(w1f), ptr(b1f), ptr(ws), nws, stream_ptr(dev)), "xnrs_fold_weights")
+    if len(_fold_cache) > 64:  # modules come and go (tests): keep the table small
+        _fold_cache.clear()
+    _fold_cache[key] = (fp, w1f, b1f)
+    return w1f, b1f
 
 
 def head_params(head):

@@ -104,10 +104,11 @@ def collapse_mask(m: torch.Tensor):
     return hm
 
 
-def _pool_args(pooler):
+def _pool_args(pooler, att=None):
+    """att: the attention stage in front of the pooler in an INFERENCE call (the cached folded fc1 rides along)."""
     from .models.components import layers
     if isinstance(pooler, layers.AdditiveAttention):
-        p, keep = hip.additive_params(pooler)
+        p, keep = hip.additive_params(pooler, att)
         return hip.POOL_ADDITIVE, p, keep
     if isinstance(pooler, layers.MaskedMean):
         return hip.POOL_MEAN, None, []
@@ -131,7 +132,7 @@ def text_encoder_forward(x: torch.Tensor, m: torch.Tensor, att, pooler, head, id
         n = ids.numel()
     else:
         n = n_tab
-    pool_kind, pp, keep = _pool_args(pooler)
+    pool_kind, pp, keep = _pool_args(pooler, att if dropout_p == 0.0 else None)
     ap = hp = None
     if att is not None:
         ap, k2 = hip.mha_params(att, dropout_p, seed)
@@ -174,7 +175,7 @@ def text_encoder_forward_unpadded(x: torch.Tensor, m: torch.Tensor, att, pooler,
         live = m2.ne(0)
         base = None
     n = live.shape[0]
-    pool_kind, pp, keep = _pool_args(pooler)
+    pool_kind, pp, keep = _pool_args(pooler, att)
     if pool_kind != hip.POOL_ADDITIVE:
         raise hip.XnrsHipError("the unpadded encoder needs the additive pooler")
     bad = ((m2 != 0) & (m2 != 1)).any()
@@ -224,7 +225,7 @@ def user_encoder_forward(x: torch.Tensor, m: torch.Tensor, att, pooler, head, re
     x = hip.dev_f32(x, "user encoder input")
     B, H, E = x.shape
     m2 = _mask2d(m, B, H, "user encoder mask")
-    pool_kind, pp, keep = _pool_args(pooler)
+    pool_kind, pp, keep = _pool_args(pooler, att if dropout_p == 0.0 else None)
     ap = hp = None
     if att is not None:
         ap, k2 = hip.mha_params(att, dropout_p, seed)
