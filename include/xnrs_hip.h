@@ -153,6 +153,24 @@ int32_t xnrs_text_encoder_fwd_unpadded(const float *x, const int32_t *ids, int64
                                        const xnrs_head_params *head, float *y, float *hm, void *ws, size_t ws_bytes,
                                        void *stream);
 
+/* ---- the same, with the row lists built ON THE DEVICE (ABI version 3) --------------------------------
+ * xnrs_text_encoder_fwd_unpadded needs the compact row lists and their count from the host (one device->host read of the
+ * counts per call).  This entry point takes the padded inputs of xnrs_text_encoder_fwd (x / m, or a table + ids) and
+ * compacts on the device: per pass of `chunk` news a single-workgroup kernel builds the CSR offsets, the live-row list
+ * and the list of token rows of the non-empty news (an all-masked news has no live query, so its K / V are never read
+ * and are not projected either); the GEMMs are launched over the worst-case row count and read the real one from
+ * device memory (tiles past it return at once).  No host sync, no data-dependent launch: the whole call can be captured
+ * in a hipGraph.  0/1 masks are a PRECONDITION here (not checked: that would be the host read this entry point exists to
+ * avoid); inference, additive pooler, fp32 GEMM mode, S <= 64, head width <= 64 and a multiple of 4 with an attention
+ * stage (XNRS_EUNSUPPORTED otherwise: use xnrs_text_encoder_fwd).  Results equal xnrs_text_encoder_fwd bit for bit for
+ * prefix masks. */
+size_t xnrs_text_encoder_compact_workspace_bytes(int64_t n_news, int32_t S, int32_t D, int32_t A, int32_t E,
+                                                 int32_t has_att, int32_t has_head, int64_t chunk);
+int32_t xnrs_text_encoder_fwd_compact(const float *x, const float *m, const int32_t *ids, int64_t n_news, int32_t S,
+                                      int32_t D, const xnrs_mha_params *att, const xnrs_additive_params *pool,
+                                      const xnrs_head_params *head, float *y, float *hm, int64_t chunk, void *ws,
+                                      size_t ws_bytes, void *stream);
+
 /* ---- UserEncoder.forward (user_encoding.py:50-81) -------------------------------------------
  * x:(B,H,E), m:(B,H) -> y:(B,E) [, a_out:(B,H) when the pooler is additive and a_out != NULL]. */
 size_t xnrs_user_encoder_workspace_bytes(int64_t B, int32_t H, int32_t E, int32_t A, int32_t has_att,

@@ -372,10 +372,13 @@ def test_unpadded_encoder_matches_padded(tower):
         enc.unpadded = enc.skip_empty = False
         assert torch.equal(y5.reshape(n, E), y0) and torch.equal(hm5.reshape(n), hm0)
         assert torch.equal(y6[0], y0[ids.long()]) and torch.equal(hm6[0, :, 0], hm0[ids.long()])
-        # a non-binary mask is refused, not mis-computed
+        # a non-binary mask is refused, not mis-computed: the host-compacted path raises (it reads the counts anyway), the
+        # device-compacted one -- no host read to raise from -- poisons its outputs with NaN
         from xnrs_amd.hip import XnrsHipError
         with pytest.raises(XnrsHipError):
-            ops.text_encoder_unpadded(x, m * 0.5, enc)
+            ops.text_encoder_forward_unpadded(x, m * 0.5, enc.att, enc.pooler, enc.head)
+        yb, hmb = ops.text_encoder_forward_compact(x, m * 0.5, enc.att, enc.pooler, enc.head)
+        assert torch.isnan(yb).all() and torch.isnan(hmb).all()
 
 
 def test_naml_with_padding_free_encoders_matches_golden():
@@ -497,3 +500,66 @@ def test_fc2_dot_in_the_fc1_epilogue(S, D, h, A):
     uo, ao = O.user_encoder(hx, hmask, usd, h, return_weights=True)
     H.assert_close(u1, uo, what="user vector vs oracle")
     H.assert_close(a1, ao, what="pooling weights vs oracle")
+
+
+@pytest.mark.parametrize("tower", ["nrms", "additive_only"])
+def test_device_compacted_encoder_and_graph_capture(tower):
+    """xnrs_text_encoder_fwd_compact: the padding-free encoder with the live-row / K|V-row lists and their counts built
+    on the DEVICE (the GEMMs read the row count from device memory).  Prefix masks: bitwise equal to the padded kernels
+    and to the host-compacted path, over several passes, with a table + ids, with all-masked and fully live news; then
+    the whole forward (skip_empty + unpadded switched on) is CAPTURED in a hipGraph -- no host sync anywhere -- and the
+    replay on new data equals the dense step bit for bit."""
+    from xnrs_amd import ops
+    S, D, h, E = 50, 192, 4, 64
+    att = layers.MultiHeadAttention(h, D) if tower == "nrms" else None
+    enc, sd = load(news_encoding.TextEncoder(pooler=layers.AdditiveAttention(D, 256), p_dropout=0.0, out_features=E,
+                                             in_features=D, att=att), 231)
+    rng = synth.rng_for(232)
+    n = 700
+    x = torch.from_numpy(rng.standard_normal((n, S, D)).astype("float32")).to(DEV)
+    L = rng.integers(0, S + 1, size=n)
+    L[:3] = (0, S, 1)
+    L[100:160] = 0  # a run of empty news (history padding)
+    m = torch.from_numpy((np.arange(S)[None, :] < L[:, None]).astype("float32")).to(DEV)
+    with torch.no_grad():
+        y0, hm0 = ops.text_encoder(x, m, enc)
+        y1, hm1 = ops.text_encoder_forward_compact(x, m, enc.att, enc.pooler, enc.head)
+        y2, hm2 = ops.text_encoder_forward_compact(x, m, enc.att, enc.pooler, enc.head, chunk=97)  # 8 ragged passes
+        y3, hm3 = ops.text_encoder_forward_unpadded(x, m, enc.att, enc.pooler, enc.head)          # host-compacted
+        assert torch.equal(hm1, hm0) and torch.equal(y1, y0)
+        assert torch.equal(hm2, hm0) and torch.equal(y2, y0)
+        assert torch.equal(hm3, hm0) and torch.equal(y3, y0)
+        ids = torch.from_numpy(rng.integers(0, n, size=(1234,)).astype("int32")).to(DEV)
+        y4, hm4 = ops.text_encoder_forward_compact(x, m, enc.att, enc.pooler, enc.head, ids=ids, chunk=300)
+        assert torch.equal(y4, y0[ids.long()]) and torch.equal(hm4, hm0[ids.long()])
+        mh = torch.from_numpy((rng.random((n, S)) < 0.5).astype("float32")).to(DEV)  # masks with holes
+        mh[0] = 0
+        y5, hm5 = ops.text_encoder(x, mh, enc)
+        y6, hm6 = ops.text_encoder_forward_compact(x, mh, enc.att, enc.pooler, enc.head)
+        assert torch.equal(hm5, hm6)
+        H.assert_close(y6, y5, tol=1e-6, what="holey masks")
+        # ---- capture: the module path with both padding-free switches on
+        enc.unpadded = enc.skip_empty = True
+        try:
+            xs, ms = x.reshape(14, 50, S, D).clone(), m.reshape(14, 50, S, 1).clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                enc((xs, ms))  # warm-up outside the capture (workspace growth, fold cache)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                yg, hmg = enc((xs, ms))
+            # replay on DIFFERENT data (other tokens, other lengths): the launch sequence did not depend on the first batch
+            L2 = rng.integers(0, S + 1, size=n)
+            L2[5:40] = 0
+            x2 = torch.from_numpy(rng.standard_normal((n, S, D)).astype("float32")).to(DEV)
+            m2 = torch.from_numpy((np.arange(S)[None, :] < L2[:, None]).astype("float32")).to(DEV)
+            xs.copy_(x2.reshape(14, 50, S, D))
+            ms.copy_(m2.reshape(14, 50, S, 1))
+            g.replay()
+            torch.cuda.synchronize()
+        finally:
+            enc.unpadded = enc.skip_empty = False
+        yd, hmd = ops.text_encoder(x2, m2, enc)
+        assert torch.equal(yg.reshape(n, E), yd) and torch.equal(hmg.reshape(n), hmd)

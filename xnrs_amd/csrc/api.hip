@@ -820,6 +820,208 @@ int32_t xnrs_text_encoder_fwd_unpadded(const float* x, const int32_t* ids, int64
   return XNRS_OK;
 }
 
+// ---- the padding-free encoder with the row lists built ON THE DEVICE (no host sync: hipGraph-capturable)
+namespace {
+struct CompactPlan {
+  int64_t chunk;
+  size_t off_kv, off_q, off_o, off_t, off_roff, off_live, off_kvs, off_kvd, off_cnt, off_p, off_h, off_fw, off_fb, off_po,
+      off_as, off_fsl, total;
+};
+CompactPlan make_compact_plan(int64_t n_news, int S, int D, int A, int E, bool att, bool head, int64_t chunk) {
+  CompactPlan p{};
+  if (chunk <= 0) chunk = 65536 / S;
+  if (chunk > n_news) chunk = n_news;
+  if (chunk < 1) chunk = 1;
+  p.chunk = chunk;
+  size_t cur = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = cur;
+    cur += (bytes + 255) / 256 * 256;
+    return o;
+  };
+  const size_t rows = (size_t)chunk * S;  // worst case of a pass: every token live
+  const int n_ep = (A + 31) / 32;
+  p.off_kv = att ? take(rows * 2 * D * 4) : 0;
+  p.off_q = att ? take(rows * D * 4) : 0;
+  p.off_o = att ? take(rows * D * 4) : 0;
+  p.off_t = take(rows * (size_t)n_ep * 4);
+  p.off_roff = take(((size_t)chunk + 1) * 8);
+  p.off_live = take(rows * 4);
+  p.off_kvs = take(rows * 4);
+  p.off_kvd = take(rows * 4);
+  p.off_cnt = take((size_t)((n_news + chunk - 1) / chunk) * 3 * 8);  // {live rows, K|V rows, bad-mask flag} per pass
+  p.off_p = head ? take((size_t)n_news * D * 4) : 0;
+  p.off_h = head ? take((size_t)n_news * E * 4) : 0;
+  p.off_fw = att ? take((size_t)A * D * 4) : 0;
+  p.off_fb = att ? take((size_t)A * 4) : 0;
+  p.off_po = att ? take((size_t)n_news * D * 4) : 0;
+  p.off_as = att ? take((size_t)n_news * 4) : 0;
+  p.off_fsl = att ? take((size_t)FOLD_SPLITS * A * D * 4) : 0;
+  p.total = cur;
+  return p;
+}
+}  // namespace
+
+size_t xnrs_text_encoder_compact_workspace_bytes(int64_t n_news, int32_t S, int32_t D, int32_t A, int32_t E, int32_t has_att,
+                                                 int32_t has_head, int64_t chunk) {
+  return make_compact_plan(n_news, S, D, A, E, has_att != 0, has_head != 0, chunk).total;
+}
+
+int32_t xnrs_text_encoder_fwd_compact(const float* x, const float* m, const int32_t* ids, int64_t n_news, int32_t S, int32_t D,
+                                      const xnrs_mha_params* att, const xnrs_additive_params* pool, const xnrs_head_params* head,
+                                      float* y, float* hm, int64_t chunk, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_news == 0) return XNRS_OK;
+  if (!x || !m || !pool || !pool->w1 || !pool->w2 || !y || n_news < 0 || S <= 0 || D <= 0 || pool->hidden <= 0) return XNRS_EINVAL;
+  if (S > 512) return XNRS_EUNSUPPORTED;
+  const int A = pool->hidden, E = head ? head->out_features : D;
+  if (att) {
+    if (att->n_heads <= 0 || D % att->n_heads != 0) return XNRS_EHEADS;
+    if (S > 64 || D / att->n_heads > 64 || (D / att->n_heads) % 4 != 0 || D % 4 != 0) return XNRS_EUNSUPPORTED;
+    if (att->dropout_p != 0.f) return XNRS_EUNSUPPORTED;  // inference only
+  }
+  // the device row counts ride on the fp32 forward kernel with the fc2 dot in its epilogue (what the padded and the
+  // host-compacted paths run too: the three stay bitwise equal)
+  if (gemm_mode() != 0 || !fc1_rowdot_ok(x, att != nullptr, pool, D)) return XNRS_EUNSUPPORTED;
+  const CompactPlan p = make_compact_plan(n_news, S, D, A, E, att != nullptr, head != nullptr, chunk);
+  if (!ws || ws_bytes < p.total) return XNRS_EWORKSPACE;
+  char* w = static_cast<char*>(ws);
+  float* kv = reinterpret_cast<float*>(w + p.off_kv);
+  float* qc = reinterpret_cast<float*>(w + p.off_q);
+  float* oc = reinterpret_cast<float*>(w + p.off_o);
+  float* tc = reinterpret_cast<float*>(w + p.off_t);
+  int64_t* roff = reinterpret_cast<int64_t*>(w + p.off_roff);
+  int32_t* live = reinterpret_cast<int32_t*>(w + p.off_live);
+  int32_t* kvs = reinterpret_cast<int32_t*>(w + p.off_kvs);
+  int32_t* kvd = reinterpret_cast<int32_t*>(w + p.off_kvd);
+  int64_t* cnt0 = reinterpret_cast<int64_t*>(w + p.off_cnt);
+  float* pb = reinterpret_cast<float*>(w + p.off_p);
+  float* hb = reinterpret_cast<float*>(w + p.off_h);
+  float* wf = reinterpret_cast<float*>(w + p.off_fw);
+  float* bf = reinterpret_cast<float*>(w + p.off_fb);
+  float* pob = reinterpret_cast<float*>(w + p.off_po);
+  float* asum = reinterpret_cast<float*>(w + p.off_as);
+  const bool fold = att && fold_wanted(knobs().fold_out);
+  const float* fc1_w = pool->w1;
+  const float* fc1_b = pool->b1;
+  if (fold) {
+    if (pool->w1_folded) {
+      fc1_w = pool->w1_folded;
+      fc1_b = att->bo ? pool->b1_folded : pool->b1;
+      if (att->bo && !pool->b1_folded) return XNRS_EINVAL;
+    } else {
+      hipError_t fe = hipSuccess;
+      fc1_b = fold_out_projection(att, pool, D, A, wf, bf, reinterpret_cast<float*>(w + p.off_fsl), stream, &fe);
+      XNRS_TRY(fe);
+      fc1_w = wf;
+    }
+  }
+  if (att && !fold) return XNRS_EUNSUPPORTED;  // (the per-token out-projection order: use the host-compacted entry point)
+  const int n_ep = (A + 31) / 32;
+  for (int64_t c0 = 0; c0 < n_news; c0 += p.chunk) {
+    const int64_t nc = (n_news - c0 < p.chunk) ? (n_news - c0) : p.chunk;
+    const int64_t rows = nc * S;  // worst case
+    int64_t* cnt = cnt0 + 3 * (c0 / p.chunk);
+    XNRS_TRY(launch_compact_rows(m, ids, c0, (int)nc, S, roff, live, kvs, kvd, cnt, stream));
+    const float* vals = x;           // what the pooler weights: compact O rows, or x rows through `live`
+    const int32_t* val_ids = live;
+    if (att) {
+      const int dk = D / att->n_heads;
+      {  // K and V of every token of the news that have a live token (rows gathered AND scattered through the device lists)
+        GemmArgs g{};
+        g.A = x;
+        g.gather_ids = kvs;
+        g.gather_S = 1;
+        g.c_scatter = 1;
+        g.c_scatter_ids = kvd;
+        g.lda = D;
+        g.W[0] = att->wk; g.W[1] = att->wv;
+        g.bias[0] = att->bk; g.bias[1] = att->bv;
+        g.nseg = 2;
+        g.Nseg = D;
+        g.ldw = D;
+        g.C = kv;
+        g.ldc = 2 * (int64_t)D;
+        g.M = rows;
+        g.m_dev = cnt + 1;
+        g.K = D;
+        ProfScope ps(0, 2.0 * rows * 3.0 * D * D, stream);  // (worst case: the row counts live on the device)
+        XNRS_TRY(launch_gemm_f32(g, stream));
+        GemmArgs q = gemm1(x, live, 1, D, att->wq, att->bq, qc, D, rows, D, D, XNRS_ACT_NONE);
+        q.m_dev = cnt;
+        XNRS_TRY(launch_gemm_f32(q, stream));
+      }
+      MhaCoreArgs ma{};
+      ma.q = qc;
+      ma.q_off = roff;
+      ma.ldq = D;
+      ma.k = kv;
+      ma.v = kv + D;
+      ma.ld = 2 * (int64_t)D;
+      ma.seq_stride = (int64_t)S * 2 * D;
+      ma.head_stride = dk;
+      ma.out = oc;
+      ma.ldo = D;
+      ma.n_seq = nc;
+      ma.S = S;
+      ma.n_heads = att->n_heads;
+      ma.d_k = dk;
+      ma.scaled = att->scaled;
+      {
+        ProfScope ps(1, 4.0 * rows * (double)S * D, stream);
+        XNRS_TRY(launch_mha_core(ma, stream));
+      }
+      vals = oc;
+      val_ids = nullptr;
+    }
+    {
+      ProfScope ps(3, 2.0 * rows * (double)D * A, stream);
+      GemmArgs fg = gemm1(vals, val_ids, 1, D, fc1_w, fc1_b, tc, A, rows, A, D, XNRS_ACT_TANH);
+      fg.rowdot_w = pool->w2;
+      fg.rowdot_out = tc;
+      fg.ldrd = n_ep;
+      fg.m_dev = cnt;
+      XNRS_TRY(launch_gemm_f32(fg, stream));
+    }
+    AdditivePoolArgs pa{};
+    pa.epart = tc;
+    pa.n_epart = n_ep;
+    pa.w2 = pool->w2;
+    pa.b2 = pool->b2;
+    pa.x = vals;
+    pa.ldx = D;
+    pa.row_off = roff;
+    pa.row_ids = val_ids;
+    pa.poison = cnt + 2;  // a mask value other than 0 / 1: NaN out, not a silently different result
+    pa.y = (fold ? pob : (head ? pb : y)) + c0 * (int64_t)D;
+    pa.asum_out = fold ? asum + c0 : nullptr;
+    pa.hm_out = hm ? hm + c0 : nullptr;
+    pa.n_seq = nc;
+    pa.N = S;
+    pa.D = D;
+    pa.A = A;
+    {
+      ProfScope ps(4, 2.0 * rows * (double)(A + D), stream);
+      XNRS_TRY(launch_additive_pool(pa, stream));
+    }
+  }
+  if (fold) {
+    float* dst = head ? pb : y;
+    ProfScope ps(2, 2.0 * n_news * (double)D * D, stream);
+    XNRS_TRY(pooled_out_projection(pob, asum, att, dst, n_news, D, nullptr, stream));
+  }
+  if (head) {
+    ProfScope ps(5, 2.0 * n_news * ((double)D * E + (double)E * E), stream);
+    XNRS_TRY(launch_gemm_f32(gemm1(pb, nullptr, 0, D, head->w0, head->b0, hb, E, n_news, E, D, head->activation), stream));
+    XNRS_TRY(launch_gemm_f32(gemm1(hb, nullptr, 0, E, head->w2, head->b2, y, E, n_news, E, E, XNRS_ACT_NONE), stream));
+  }
+  // a mask value other than 0 / 1 in any pass: NaN over the whole result (a ReLU head would swallow a NaN fed in earlier)
+  const int n_pass = (int)((n_news + p.chunk - 1) / p.chunk);
+  XNRS_TRY(launch_poison(y, n_news * (int64_t)E, cnt0 + 2, n_pass, 3, stream));
+  if (hm) XNRS_TRY(launch_poison(hm, n_news, cnt0 + 2, n_pass, 3, stream));
+  return XNRS_OK;
+}
+
 size_t xnrs_user_encoder_workspace_bytes(int64_t B, int32_t H, int32_t E, int32_t A, int32_t has_att, int32_t pool_kind,
                                          int32_t has_head) {
   return make_plan(B, H, E, A, E, has_att != 0, pool_kind == XNRS_POOL_ADDITIVE, has_head != 0, true, 0).total;

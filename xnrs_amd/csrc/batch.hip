@@ -233,4 +233,104 @@ hipError_t launch_gather_rows(const float* table, const int32_t* ids, float* out
   return hipGetLastError();
 }
 
+// ---- row compaction on the device (the padding-free encoder without a host round trip).
+// For the cn news of one pass (mask [.., S] fp32 0/1, optionally gathered by news id): CSR offsets of the live token rows
+// per news, the list of live token rows, and the list of ALL token rows of the non-empty news (K / V are projected for
+// every token of a news that has a live query: the reference masks QUERY rows only, layers.py:142-144 -- and for none of
+// an all-masked news, whose keys nobody reads).  ONE workgroup: cn <= a few thousand, two scans of cn counts.
+//   row_off [cn+1]   compact range of news j: row_off[j] .. row_off[j+1]
+//   live_src [<= cn*S]  source token row (x row space: ids[news]*S + s with a table, else (news0 + j)*S + s) of compact row i
+//   kv_src / kv_dst [<= cn*S]  source row / row inside this pass's padded [cn*S] K|V image of the i-th kept token row
+//   counts[0] = live rows, counts[1] = kept K|V rows      (device scalars the GEMMs read: GemmArgs::m_dev)
+//   counts[2] = 1 if a mask value other than 0 / 1 was seen: the pooling kernel then writes NaN instead of a result that
+//               would silently differ from the reference's exp(e) * m (there is no host read here to raise from)
+__global__ __launch_bounds__(1024) void compact_rows_kernel(const float* __restrict__ mask, const int32_t* __restrict__ ids,
+                                                             int64_t news0, int cn, int S, int64_t* __restrict__ row_off,
+                                                             int32_t* __restrict__ live_src, int32_t* __restrict__ kv_src,
+                                                             int32_t* __restrict__ kv_dst, int64_t* __restrict__ counts) {
+  __shared__ int s_scan[1024];
+  __shared__ int s_carry[2];
+  const int tid = threadIdx.x;
+  int bad = 0;
+  if (tid < 2) s_carry[tid] = 0;
+  if (tid == 0) row_off[0] = 0;
+  __syncthreads();
+  for (int base = 0; base < cn; base += 1024) {
+    const int j = base + tid;
+    int cnt = 0;
+    int64_t mrow = 0;
+    if (j < cn) {
+      mrow = ids ? (int64_t)ids[news0 + j] : news0 + j;
+      const float* mp = mask + mrow * S;
+      for (int s = 0; s < S; ++s) {
+        const float mv = mp[s];
+        cnt += mv != 0.f ? 1 : 0;
+        bad |= (mv != 0.f && mv != 1.f) ? 1 : 0;
+      }
+    }
+    // inclusive scans of (live count) and (kept K|V rows = S for a non-empty news) over the 1024 threads of this pass
+    int v[2] = {cnt, cnt > 0 ? S : 0};
+    int excl[2];
+    for (int which = 0; which < 2; ++which) {
+      s_scan[tid] = v[which];
+      __syncthreads();
+      for (int off = 1; off < 1024; off <<= 1) {
+        const int add = tid >= off ? s_scan[tid - off] : 0;
+        __syncthreads();
+        s_scan[tid] += add;
+        __syncthreads();
+      }
+      excl[which] = s_carry[which] + s_scan[tid] - v[which];
+      __syncthreads();
+      if (tid == 1023) s_carry[which] += s_scan[1023];
+      __syncthreads();
+    }
+    if (j < cn) {
+      row_off[j + 1] = excl[0] + cnt;
+      const int64_t src0 = mrow * S;  // source token row of (news, 0)
+      const float* mp = mask + mrow * S;
+      int w = excl[0];
+      for (int s = 0; s < S; ++s)
+        if (mp[s] != 0.f) live_src[w++] = (int32_t)(src0 + s);
+      if (cnt > 0) {
+        for (int s = 0; s < S; ++s) {
+          kv_src[excl[1] + s] = (int32_t)(src0 + s);
+          kv_dst[excl[1] + s] = j * S + s;
+        }
+      }
+    }
+  }
+  bad = __syncthreads_or(bad);
+  if (tid == 0) {
+    counts[0] = s_carry[0];
+    counts[1] = s_carry[1];
+    counts[2] = bad ? 1 : 0;
+  }
+}
+
+// NaN over a result whose precondition turned out violated on the device (the flags of every pass, OR-ed)
+__global__ __launch_bounds__(256) void poison_kernel(float* y, int64_t n, const int64_t* flags, int n_flags, int flag_stride) {
+  bool bad = false;
+  for (int i = 0; i < n_flags; ++i) bad = bad || flags[(int64_t)i * flag_stride] != 0;
+  if (!bad) return;
+  const float nanv = __builtin_nanf("");
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = nanv;
+}
+
+hipError_t launch_poison(float* y, int64_t n, const int64_t* flags, int n_flags, int flag_stride, hipStream_t stream) {
+  if (n <= 0 || n_flags <= 0) return hipSuccess;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(poison_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, y, n, flags, n_flags, flag_stride);
+  return hipGetLastError();
+}
+
+hipError_t launch_compact_rows(const float* mask, const int32_t* ids, int64_t news0, int cn, int S, int64_t* row_off,
+                               int32_t* live_src, int32_t* kv_src, int32_t* kv_dst, int64_t* counts, hipStream_t stream) {
+  if (cn <= 0) return hipSuccess;
+  hipLaunchKernelGGL(compact_rows_kernel, dim3(1), dim3(1024), 0, stream, mask, ids, news0, cn, S, row_off, live_src, kv_src,
+                     kv_dst, counts);
+  return hipGetLastError();
+}
+
 }  // namespace xnrs

@@ -124,6 +124,13 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
   const int nts = nt - seg * n_tiles_seg;
   const int64_t m0 = (int64_t)mt * BM;
   const int n0 = nts * BN;  // column inside the segment
+  if constexpr (!A_COL && !B_KN) {
+    if (a.m_dev) {  // the row count is a device scalar (GemmArgs::m_dev): a.M was only the grid's worst case
+      const int64_t md = *a.m_dev;
+      if (m0 >= md) return;  // workgroup-uniform, before any barrier
+      a.M = md;
+    }
+  }
 
   // contraction indices are 32-bit in the kernel (the launcher refuses K >= 2^31): the k-tail tests and tile offsets of
   // the inner loop are then single VALU / SALU instructions instead of 64-bit compare-and-select pairs
@@ -870,6 +877,7 @@ hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t stream, int* nsplit
   // the split kernel has one tile shape (128x128): below one full round of workgroups the fp32 kernel with its
   // smaller tiles is faster (measured: 4099 x 260 x 300 -> 38 TF fp32 vs 22 TF split)
   const int64_t min_tiles = knobs().split_min_tiles;  // tests force the split kernel onto tiny shapes with 0
+  if (a.m_dev && (a.a_col || a.b_kn || nsplit != 1 || mode != 0)) return hipErrorInvalidValue;  // device row count: fp32 forward only
   if (a.rowscale && (a.a_col || a.b_kn || a.nseg != 1 || nsplit != 1 || !a.rowscale_vec || a.c_scatter || a.rowdot_out))
     return hipErrorInvalidValue;  // rank-1 epilogue term: plain forward launches only
   if (mode && !a.rowdot_out && !a.rowscale && !a.a_col && !a.b_kn && vec && nsplit == 1 &&

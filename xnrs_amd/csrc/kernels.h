@@ -96,6 +96,10 @@ struct GemmArgs {
   // rowscale_vec[n], acc) before bias / activation (the out-projection bias behind a pooled out-projection: bo * sum_i a_i)
   const float* rowscale;
   const float* rowscale_vec;
+  // forward layout (nullable): the row count lives on the DEVICE -- M is the worst case the grid is sized for, *m_dev
+  // (<= M) the rows that exist; tiles past it return at once.  (Row lists compacted on the device: no host round trip,
+  // the launch sequence does not depend on the data and can be captured in a hipGraph.)
+  const int64_t* m_dev;
   // split-K (deterministic slabs + ordered reduce); set by the caller via slabs/nsplit
   float* slabs;        // nullable workspace of nsplit * M * ldc floats
   int32_t nsplit;
@@ -347,6 +351,8 @@ struct AdditivePoolArgs {
   // (x_gather_ids unused); every compact row is unmasked, `mask` is ignored and hm_out = (count > 0).
   const int64_t* row_off;
   const int32_t* row_ids;  // nullable, with row_off: value row of compact row j is x[row_ids[j]] (t stays compact)
+  const int64_t* poison;   // nullable device flag: non-zero -> every output of the launch is NaN (a precondition the host
+                           // could not check without a sync was violated: launch_compact_rows saw a non-0/1 mask)
 };
 hipError_t launch_additive_pool(const AdditivePoolArgs& a, hipStream_t stream);
 // p[n][d] += s[n] * b[d]   (the out-projection bias behind a pooled out-projection, api.hip "fold")
@@ -427,6 +433,10 @@ struct BatchArgs {
 // out[i, :] = table[ids[i], :] for rows of row_floats floats (whole news blocks)
 hipError_t launch_gather_rows(const float* table, const int32_t* ids, float* out, int64_t n, int64_t row_floats,
                               hipStream_t stream);
+hipError_t launch_poison(float* y, int64_t n, const int64_t* flags, int n_flags, int flag_stride, hipStream_t stream);
+// live-row / kept-K|V-row lists + CSR offsets of one pass of news, built on the device (batch.hip)
+hipError_t launch_compact_rows(const float* mask, const int32_t* ids, int64_t news0, int cn, int S, int64_t* row_off,
+                               int32_t* live_src, int32_t* kv_src, int32_t* kv_dst, int64_t* counts, hipStream_t stream);
 hipError_t launch_assemble_train(const BatchArgs& a, hipStream_t stream);
 hipError_t launch_assemble_eval(const BatchArgs& a, hipStream_t stream);
 hipError_t launch_score_csr(const float* vecs, const int32_t* rows, const int32_t* sess, const float* u, float* r, int64_t n,

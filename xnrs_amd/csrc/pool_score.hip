@@ -70,11 +70,13 @@ __global__ __launch_bounds__(256) void additive_pool_kernel(AdditivePoolArgs a) 
   const float sumw = s_red[0] + s_red[1] + s_red[2] + s_red[3];
   const float denom = sumw + 1e-8f;
   __syncthreads();
-  if (a.asum_out && tid == 0) a.asum_out[seq] = sumw / denom;
+  const bool poisoned = a.poison && *a.poison != 0;
+  const float nanv = __builtin_nanf("");
+  if (a.asum_out && tid == 0) a.asum_out[seq] = poisoned ? nanv : sumw / denom;
   if (a.hm_out) {
     if (lane == 0) s_red[wave] = mpart;
     __syncthreads();
-    if (tid == 0) a.hm_out[seq] = fminf(fmaxf(s_red[0] + s_red[1] + s_red[2] + s_red[3], 0.f), 1.f);
+    if (tid == 0) a.hm_out[seq] = poisoned ? nanv : fminf(fmaxf(s_red[0] + s_red[1] + s_red[2] + s_red[3], 0.f), 1.f);
   }
   if (a.a_out)
     for (int i = tid; i < N; i += 256) a.a_out[r0 + i] = s_w[i] / denom;
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void additive_pool_kernel(AdditivePoolArgs a) 
     } else {
       for (int i = 0; i < N; ++i) acc = fmaf(s_w[i] / denom, x[(int64_t)i * a.ldx + d], acc);
     }
-    a.y[seq * D + d] = acc;
+    a.y[seq * D + d] = poisoned ? nanv : acc;
   }
 }
 

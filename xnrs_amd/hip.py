@@ -33,6 +33,7 @@ SYMBOLS = (
     "xnrs_assemble_train_batch", "xnrs_assemble_eval_batch", "xnrs_score_csr", "xnrs_rank_metrics", "xnrs_gather_rows",
     "xnrs_infonce_saved_bytes", "xnrs_infonce_fwd", "xnrs_infonce_bwd", "xnrs_train_fold_enabled",
     "xnrs_fold_weights_workspace_bytes", "xnrs_fold_weights",
+    "xnrs_text_encoder_compact_workspace_bytes", "xnrs_text_encoder_fwd_compact",
 )
 POOL_NONE = -1
 PROFILE_STAGES = ("qkv_gemm", "attention_core", "out_gemm", "fc1_tanh_gemm", "pool", "head_gemms", "news_fused",
@@ -177,6 +178,11 @@ def lib():
     l.xnrs_profile_read.argtypes = [p, p, p]
     l.xnrs_train_fold_enabled.restype = i32
     l.xnrs_train_fold_enabled.argtypes = []
+    l.xnrs_text_encoder_compact_workspace_bytes.restype = sz
+    l.xnrs_text_encoder_compact_workspace_bytes.argtypes = [i64, i32, i32, i32, i32, i32, i32, i64]
+    l.xnrs_text_encoder_fwd_compact.restype = i32
+    l.xnrs_text_encoder_fwd_compact.argtypes = [p, p, p, i64, i32, i32, C.POINTER(MhaParams), C.POINTER(AdditiveParams),
+                                                C.POINTER(HeadParams), p, p, i64, p, sz, p]
     l.xnrs_fold_weights_workspace_bytes.restype = sz
     l.xnrs_fold_weights_workspace_bytes.argtypes = [i32, i32]
     l.xnrs_fold_weights.restype = i32

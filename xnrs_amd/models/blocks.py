@@ -113,6 +113,11 @@ class TextEncoder(_Tower):
         b, n, s, d = x.shape
         xf, mf = self.dropout(x.reshape(b * n, s, d)), m.reshape(b * n, s, 1)
         encode = self._encoder_fn()
+        if encode is ops.text_encoder_unpadded and ops.COMPACT_ON_DEVICE and ops.compact_supported(s, d, self.att, self.pooler) \
+                and not (self.att is not None and self.att.training and self.att.dropout.p > 0):
+            # the device-compacted padding-free encoder drops empty news by itself: no host-side list, no sync
+            y, hm = encode(xf, mf, self)
+            return y.reshape(b, n, self.out_dim), hm.reshape(b, n, 1)
         if self.skip_empty and not (torch.is_grad_enabled() and xf.requires_grad):  # no input gradient through a gather
             live = mf.reshape(b * n, s).ne(0).any(dim=1)
             idx = live.nonzero().squeeze(1)

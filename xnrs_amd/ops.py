@@ -7,6 +7,7 @@ singleton dim exactly as the reference passes them.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -219,6 +220,57 @@ def text_encoder_forward_unpadded(x: torch.Tensor, m: torch.Tensor, att, pooler,
     return y, hm
 
 
+def text_encoder_forward_compact(x: torch.Tensor, m: torch.Tensor, att, pooler, head, ids: Optional[torch.Tensor] = None,
+                                 chunk: int = 0):
+    """The padding-free encoder with the row lists built on the DEVICE (include/xnrs_hip.h: xnrs_text_encoder_fwd_compact):
+    same inputs and results as text_encoder_forward for 0/1 masks, no host sync anywhere -- the call can be captured in a
+    hipGraph.  Raises XnrsHipError(code -4) for shapes / modes it does not serve (see compact_supported)."""
+    x = hip.dev_f32(x, "text encoder input")
+    n_tab, S, D = x.shape
+    m2 = _mask2d(m, n_tab, S, "text encoder mask")
+    if ids is not None:
+        if not ids.is_cuda:
+            raise hip.XnrsHipError("ids must live on the HIP device")
+        ids = ids.to(torch.int32).contiguous()
+        n = ids.numel()
+    else:
+        n = n_tab
+    pool_kind, pp, keep = _pool_args(pooler, att)
+    if pool_kind != hip.POOL_ADDITIVE:
+        raise hip.XnrsHipError("the compact encoder needs the additive pooler")
+    ap = hp = None
+    if att is not None:
+        ap, k2 = hip.mha_params(att, 0.0, 0)
+        keep += k2
+    if head is not None:
+        hp, k3 = hip.head_params(head)
+        keep += k3
+    A, E = pp.hidden, (hp.out_features if hp is not None else D)
+    y = torch.empty((n, E), dtype=torch.float32, device=x.device)
+    hm = torch.empty((n,), dtype=torch.float32, device=x.device)
+    l = hip.lib()
+    nbytes = l.xnrs_text_encoder_compact_workspace_bytes(n, S, D, A, E, int(att is not None), int(head is not None), chunk)
+    ws = hip.workspace(x.device, nbytes)
+    hip.check(l.xnrs_text_encoder_fwd_compact(hip.ptr(x), hip.ptr(m2), hip.ptr(ids), n, S, D, None if ap is None else C.byref(ap),
+                                              C.byref(pp), None if hp is None else C.byref(hp), hip.ptr(y), hip.ptr(hm), chunk,
+                                              hip.ptr(ws), nbytes, hip.stream_ptr(x.device)), "xnrs_text_encoder_fwd_compact")
+    return y, hm
+
+
+def compact_supported(S: int, D: int, att, pooler) -> bool:
+    """Mirror of the C entry point's preconditions that can be decided on the host without touching the data."""
+    from .models.components import layers
+    if not isinstance(pooler, layers.AdditiveAttention) or hip.get_gemm_mode() != 0 or D % 4 != 0 or S > 512:
+        return False
+    if os.environ.get("XNRS_FC1_ROWDOT", "1") == "0" or os.environ.get("XNRS_GEMM_BUF", "1") == "0":
+        return False
+    if att is not None:
+        dk = D // att.h
+        if S > 64 or dk > 64 or dk % 4 != 0 or os.environ.get("XNRS_FOLD_OUT", "1") == "0":
+            return False
+    return True
+
+
 def user_encoder_forward(x: torch.Tensor, m: torch.Tensor, att, pooler, head, return_weights: bool = False,
                          dropout_p: float = 0.0, seed: int = 0):
     """UserEncoder.forward core (user_encoding.py:69-81).  x:(B,H,E), m:(B,H,1) -> (B,1,E) [,(B,H,1)]."""
@@ -339,7 +391,15 @@ def text_encoder_unpadded(x, m, enc, ids=None):
     supported = S <= 64 and D % 4 == 0 and (att is None or (dk <= 64 and dk % 4 == 0))
     if _needs_grad(x, enc) or p > 0.0 or not supported:
         return text_encoder(x, m, enc, ids=ids)
+    if COMPACT_ON_DEVICE and compact_supported(S, D, att, pooler):
+        # row lists built on the device: no host sync, capturable; all-masked news cost nothing (so skip_empty's host-side
+        # compaction is not needed on top)
+        return text_encoder_forward_compact(x, m, att, pooler, head, ids=ids)
     return text_encoder_forward_unpadded(x, m, att, pooler, head, ids=ids)
+
+
+#: TextEncoder.unpadded compacts on the device when the shape allows (XNRS_COMPACT_ON_DEVICE=0: always the host-compacted path)
+COMPACT_ON_DEVICE = os.environ.get("XNRS_COMPACT_ON_DEVICE", "1") != "0"
 
 
 def user_encoder(x, m, enc, return_weights=False):
