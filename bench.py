@@ -561,12 +561,14 @@ def gather_roofline(device, n_news=16384, n=512 * 55, reps=5):
         del x
     out["achieved"], out["frac"] = out["uniform"]["achieved"], out["uniform"]["frac"]
     out["traffic"] = None
-    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
-    if os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        out["traffic"] = tj.get("gather_rows_hbm_bytes_per_launch")
-        out["traffic_source"] = {"file": "profiles/r02_traffic.json", "commit": tj.get("commit"), "date": tj.get("date"),
-                                 "note": tj.get("gather_note")}
+    for tname in ("r03_traffic.json", "r02_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            out["traffic"] = tj.get("gather_rows_hbm_bytes_per_launch")  # null when that round's gather run was not profiled
+            out["traffic_source"] = {"file": "profiles/" + tname, "commit": tj.get("commit"), "date": tj.get("date"),
+                                     "note": tj.get("gather_note")}
+            break
     return out
 
 
@@ -840,14 +842,24 @@ def main():
         ach = (q_fl / max(q_n, 1)) / (q_ms / max(q_n, 1) * 1e-3) / 1e12 if q_n else 0.0
         # `traffic` cannot be measured in this run (PMC counters need rocprofv3 around the process): it is read from the
         # committed PMC summary of the SAME kernel and launch shape and labelled with where and when that was taken
+        # The counters were taken on ONE launch shape -- a full 65 500-row pass -- so `traffic` sits next to the algorithmic
+        # bytes of THAT launch (`traffic_launch`), not next to the mean over this run's mixed launches; null when the file
+        # does not say which launch it measured.
         traffic, traffic_source = None, None
-        for tname in ("r02_traffic.json", "r01_traffic.json"):
+        for tname in ("r03_traffic.json", "r02_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
+                launch = tj.get("qkv_launch") or ({"rows": 65500, "grid_threads": 2359296} if "65 500-row pass" in str(tj.get("kernel")) else None)
+                if launch is None:
+                    continue
                 traffic = tj.get("qkv_gemm_hbm_bytes_per_launch")
                 traffic_source = {"file": "profiles/" + tname, "commit": tj.get("commit"), "date": tj.get("date"),
-                                  "kernel": tj.get("kernel"), "method": tj.get("method", "rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE, separate passes")}
+                                  "kernel": tj.get("kernel"), "method": tj.get("method", "rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE, separate passes"),
+                                  "traffic_launch": dict(launch, alg_bytes=tj.get("algorithmic_bytes_per_launch"),
+                                                         note="the counters belong to this launch shape: compare `traffic` with ITS "
+                                                              "alg_bytes; roofline.alg_bytes_per_launch is the mean over this run's launches "
+                                                              "(the last pass of every call is shorter)")}
                 break
         out = {
             "metric": "impressions/sec (encode+score) on MIND-shaped batches",

@@ -528,9 +528,13 @@ def test_folded_out_projection_gradients(live, bias):
     m[3] = 1
     w = torch.from_numpy(rng.standard_normal((n, E)).astype("float32")).to(DEV)
 
+    took_live = []
+
     def run(knob):
         with hip.knobs(XNRS_FOLD_TRAIN=knob):
             AG.LIVE_ROWS = live
+            old_min, AG.LIVE_ROWS_MIN = AG.LIVE_ROWS_MIN, 1  # 150 x 24 = 3 600 rows: below the production threshold of 4 096
+            before = AG.STATS["live_row_forwards"]
             try:
                 enc.zero_grad(set_to_none=True)
                 xd = x.to(DEV).requires_grad_(True)
@@ -538,10 +542,13 @@ def test_folded_out_projection_gradients(live, bias):
                 (y[0] * w).sum().backward()
             finally:
                 AG.LIVE_ROWS = True
+                AG.LIVE_ROWS_MIN = old_min
+            took_live.append(AG.STATS["live_row_forwards"] > before)
         return y.detach(), xd.grad, {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None}
 
     y0, dx0, g0 = run("0")
     y1, dx1, g1 = run("2")
+    assert all(took_live) == live and any(took_live) == live  # the live-row branch really ran (or really did not)
     assert not torch.equal(y1, y0)  # (really two different computations)
     H.assert_close(y1, y0, 2e-5, "forward, folded vs per-token")
     H.assert_close(dx1, dx0, 5e-5, "dx, folded vs per-token")

@@ -21,6 +21,7 @@ import trace_summary  # noqa: E402
 
 tag = sys.argv[1]
 rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
+gather_tag = sys.argv[3] if len(sys.argv) > 3 else None  # a tools/gpu_gather.sh run (gpurun_out/prof_<gather_tag>), optional
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 
@@ -64,15 +65,29 @@ rows_, D = 65500, 768
 alg = rows_ * D * 4 + 3 * D * D * 4 + rows_ * 3 * D * 4
 commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 dirty = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "xnrs_amd/csrc"], capture_output=True, text=True).stdout.strip())
-# gather-only kernel (xnrs_gather_rows, 28 160 uniform ids into the 65 536-news table): profiles/r02_gather_rocprof.txt
-gather_fetch_kb, gather_write_kb = 2.1121e6, 4.2241e6
+# gather-only kernel (xnrs_gather_rows, 28 160 uniform ids into the 65 536-news table): counters of THIS round's
+# tools/gpu_gather.sh run when its directory is given, else no figure at all (never a number copied from an older run)
+gather_bytes, gather_note = None, "no tools/gpu_gather.sh run was passed to tools/refresh_profiles.py: no counter traffic for the gather kernel"
+if gather_tag:
+    gsrc = os.path.join(ROOT, "gpurun_out", f"prof_{gather_tag}")
+
+    def gcounter(passname, name):
+        cc = glob.glob(os.path.join(gsrc, f"uniform_pmc_{passname}", "**", "*counter_collection.csv"), recursive=True)
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(cc[0])) if r["Counter_Name"] == name and "gather_rows" in r["Kernel_Name"]
+                and int(r["Grid_Size"]) > 1000000] if cc else []
+        return sum(vals) / len(vals) if vals else None
+    gf, gw = gcounter("fetch", "FETCH_SIZE"), gcounter("write", "WRITE_SIZE")
+    if gf is not None and gw is not None:
+        gather_bytes = int((2 * gf + gw) * 1024)
+        gather_note = (f"gather_rows_kernel<true>, 28 160 uniform ids x 153 600-B news rows out of a 10-GB table: FETCH_SIZE {gf:.5g} KB (x2), "
+                       f"WRITE_SIZE {gw:.5g} KB (tools/gpu_gather.sh {gather_tag}, this binary)")
 json.dump({
     "commit": commit + ("+uncommitted csrc changes" if dirty else ""),
     "date": datetime.date.today().isoformat(),
     "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes with --kernel-trace only; bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB)",
-    "gather_rows_hbm_bytes_per_launch": int((2 * gather_fetch_kb + gather_write_kb) * 1024),
-    "gather_note": "gather_rows_kernel<true>, 28 160 uniform ids x 153 600-B news rows out of a 10-GB table: FETCH_SIZE 2.1121e6 KB (x2), "
-                   "WRITE_SIZE 4.2241e6 KB = 8.65 GB = 1.00x of read + write (profiles/r02_gather_rocprof.txt, tools/gpu_gather.sh)",
+    "gather_rows_hbm_bytes_per_launch": gather_bytes,
+    "gather_note": gather_note,
+    "qkv_launch": {"rows": rows_, "grid_threads": 2359296, "what": "one full 65 500-row pass (the last pass of a call is shorter)"},
     "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), tools/gpu_profile.sh {tag}, MI355X; "
               f"see profiles/{rnd}_rocprof_news_encoder_pass.txt",
     "kernel": "gemm_f32_kernel<2,2,false,false,true,5,16,true,4,false,2> grid 2359296 (fused Q/K/V projection of one 65 500-row pass)",

@@ -80,6 +80,8 @@ def _ref(s):
 LIVE_ROWS = os.environ.get("XNRS_BWD_LIVE_ROWS", "1") != "0"
 LIVE_ROWS_MAX_FRACTION = 0.9
 LIVE_ROWS_MIN = 4096  # token rows from which the live-row path pays for its index bookkeeping (tests lower it)
+#: how many training forwards took the live-row path (tests assert that the branch they mean to cover really ran)
+STATS = {"live_row_forwards": 0}
 
 
 class _SeqEncode(torch.autograd.Function):
@@ -110,6 +112,7 @@ class _SeqEncode(torch.autograd.Function):
             rows_live = lm.nonzero().squeeze(1)
             if rows_live.numel() <= LIVE_ROWS_MAX_FRACTION * n * L:
                 live, n_live = rows_live.to(torch.int32), rows_live.numel()
+                STATS["live_row_forwards"] += 1
                 if ids is not None:
                     seq = torch.div(rows_live, L, rounding_mode="floor")
                     live_src = (ids.long()[seq] * L + (rows_live - seq * L)).to(torch.int32)

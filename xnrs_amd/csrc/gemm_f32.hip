@@ -80,9 +80,13 @@ constexpr unsigned BUF_OOB = 0x40000000u;
 // (`if (gather_ids) { if (S == 1) ...`) sat in front of each of the 8 tile loads of an iteration: 29 basic blocks, the
 // interleaved MFMA / load schedule gone, 3.4 VALU instructions per MFMA and 65 % matrix-pipe occupancy in the dW GEMMs
 // (profiles/r02_train_step_pmc.txt).
+// MDEV (forward layout): the row count is a device scalar (GemmArgs::m_dev), read once into SGPRs -- its own
+// instantiations (a first version wrote it into the by-value argument block: that moved the whole 400-byte struct to
+// scratch in EVERY variant -- 59 spilled VGPRs in the main forward kernel, 140 -> 84 TFLOP/s).
 template <int TM, int TN, bool A_COL, bool B_KN, bool VEC, int PIPE, int BK, bool BUF = false, int MINW = 2, bool GATH = false,
-          int KG = 2, bool RDOT = false>
-__global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_tiles, int n_tiles_seg, int gn) {
+          int KG = 2, bool RDOT = false, bool MDEV = false>
+__global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmArgs a, int m_tiles, int n_tiles_seg, int gn) {
+  static_assert(!MDEV || (!A_COL && !B_KN), "device row counts: forward layout only");
   static_assert(!BUF || (!A_COL && !B_KN && VEC), "buffer loads are implemented for the forward layout");
   static_assert(!RDOT || PIPE == 5, "the fused row dots ride on the interleaved pipeline (its MFMA call is the swapped one)");
   static_assert(!GATH || BUF, "the gathered-A variant keeps buffer loads for B");
@@ -124,12 +128,12 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
   const int nts = nt - seg * n_tiles_seg;
   const int64_t m0 = (int64_t)mt * BM;
   const int n0 = nts * BN;  // column inside the segment
-  if constexpr (!A_COL && !B_KN) {
-    if (a.m_dev) {  // the row count is a device scalar (GemmArgs::m_dev): a.M was only the grid's worst case
-      const int64_t md = *a.m_dev;
-      if (m0 >= md) return;  // workgroup-uniform, before any barrier
-      a.M = md;
-    }
+  // rows that exist: a.M, or -- MDEV -- the device scalar *a.m_dev (a.M was only the grid's worst case), kept in SGPRs
+  int64_t Mrun = a.M;
+  if constexpr (MDEV) {
+    const int64_t md = *a.m_dev;
+    Mrun = ((int64_t)__builtin_amdgcn_readfirstlane((int)(md >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)md);
+    if (m0 >= Mrun) return;  // workgroup-uniform, before any barrier
   }
 
   // contraction indices are 32-bit in the kernel (the launcher refuses K >= 2^31): the k-tail tests and tile offsets of
@@ -170,13 +174,13 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
   int dA = 0, dB = 0;
   __amdgpu_buffer_rsrc_t rsA, rsB;
   if constexpr (BUF) {
-    if constexpr (!GATH) rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, (int)(a.M * a.lda * 4), 0x00020000);
+    if constexpr (!GATH) rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, (int)(Mrun * a.lda * 4), 0x00020000);
     rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, (int)((int64_t)a.Nseg * a.ldw * 4), 0x00020000);
     if constexpr (GATH) {
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
         const int64_t gr = m0 + lr + RPP * i;
-        int64_t src = gr < a.M ? gr : a.M - 1;
+        int64_t src = gr < Mrun ? gr : Mrun - 1;
         if (a.gather_ids) {
           const int64_t n = src / a.gather_S;
           src = (int64_t)a.gather_ids[n] * a.gather_S + (src - n * a.gather_S);
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
       }
     } else {
       const int64_t gr = m0 + lr;
-      offA0 = gr < a.M ? (unsigned)((gr * a.lda + 4 * lc) * 4) : BUF_OOB;
+      offA0 = gr < Mrun ? (unsigned)((gr * a.lda + 4 * lc) * 4) : BUF_OOB;
       dA = (int)(RPP * a.lda * 4);
     }
     const int col = n0 + lr;
@@ -199,8 +203,8 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       int64_t gr = m0 + lr + RPP * i;
-      if (gr < a.M) a_ok |= 1u << i;
-      else gr = a.M - 1;
+      if (gr < Mrun) a_ok |= 1u << i;
+      else gr = Mrun - 1;
       int64_t src = gr;
       if (a.gather_ids) {
         const int64_t n = gr / a.gather_S;
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
       pa[i] = a.A + src * a.lda;
     }
   } else {
-    if (m0 + 4 * cA < a.M) a_ok = 1;
+    if (m0 + 4 * cA < Mrun) a_ok = 1;
   }
   if (!B_KN) {
 #pragma unroll
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
           if (kok) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              if (mi + e < a.M) v[e] = ptr[mi + e];
+              if (mi + e < Mrun) v[e] = ptr[mi + e];
           }
           ra[p][i] = v;
         }
@@ -530,10 +534,10 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
         f32x4 v = red[cA];
 #pragma unroll
         for (int r = 1; r < KRA; ++r) v += red[r * CHA + cA];
-        float* dst = a.colsum + (int64_t)blockIdx.y * a.M + m0 + 4 * cA;
+        float* dst = a.colsum + (int64_t)blockIdx.y * Mrun + m0 + 4 * cA;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (m0 + 4 * cA + e < a.M) dst[e] = v[e];
+          if (m0 + 4 * cA + e < Mrun) dst[e] = v[e];
       }
     }
   }
@@ -561,13 +565,11 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int cb = wn * 32 * TN + 32 * j;  // first column of the block inside the tile
-        float2 bw[16];
-        rowdot_load_bw(bw, s_bw + cb, half);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          const float sc = rowdot_block_t<decltype(FAST)::value>(acc[i][j], bw);
+          const float sc = rowdot_block_t_lds<decltype(FAST)::value>(acc[i][j], s_bw + cb, half);
           const int64_t row = m0 + wm * 32 * TM + 32 * i + (lane & 31);
-          if (lane < 32 && row < a.M && n0 + cb < a.Nseg) a.rowdot_out[row * a.ldrd + ((n0 + cb) >> 5)] = sc;
+          if (lane < 32 && row < Mrun && n0 + cb < a.Nseg) a.rowdot_out[row * a.ldrd + ((n0 + cb) >> 5)] = sc;
         }
       }
     };
@@ -586,7 +588,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(GemmArgs a, int m_t
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         int64_t row = m0 + wm * 32 * TM + 32 * i + (e & 3) + 8 * (e >> 2) + crow;
-        if (row < a.M) {
+        if (row < Mrun) {
           if (!A_COL && a.c_scatter) {  // row subset in place: C (and aux) rows follow A's gather
             const int64_t n = row / a.gather_S;
             row = (int64_t)(a.c_scatter_ids ? a.c_scatter_ids : a.gather_ids)[n] * a.gather_S + (row - n * a.gather_S);
@@ -698,6 +700,24 @@ static hipError_t launch_cfg(const GemmArgs& a, bool vec, int nsplit, hipStream_
   hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, A_COL, B_KN, true, 5, 16, true, MINWV, true>), g, dim3(256), 0, stream, a, \
                      (int)m_tiles, n_tiles_seg, gn)
   if constexpr (!A_COL && !B_KN) {
+    if (a.m_dev) {  // device row count (the device-compacted padding-free encoder): its own instantiations
+      if (!vec || !(buf || gath)) return hipErrorInvalidValue;
+      if (a.rowdot_out) {
+        if (buf)
+          hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, false, false, true, 5, 16, true, 4, false, 2, true, true>), g, dim3(256), 0,
+                             stream, a, (int)m_tiles, n_tiles_seg, gn);
+        else
+          hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, false, false, true, 5, 16, true, 4, true, 2, true, true>), g, dim3(256), 0,
+                             stream, a, (int)m_tiles, n_tiles_seg, gn);
+      } else if (buf) {
+        hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, false, false, true, 5, 16, true, 4, false, 2, false, true>), g, dim3(256), 0,
+                           stream, a, (int)m_tiles, n_tiles_seg, gn);
+      } else {
+        hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, false, false, true, 5, 16, true, 4, true, 2, false, true>), g, dim3(256), 0,
+                           stream, a, (int)m_tiles, n_tiles_seg, gn);
+      }
+      return hipGetLastError();
+    }
     if (a.rowdot_out) {  // fused row dots: its own instantiation, so that the plain kernel's registers stay as they are
       if (!vec || !(buf || gath)) return hipErrorInvalidValue;
       if (buf)

@@ -239,6 +239,23 @@ __device__ __forceinline__ float rowdot_block_t(const f32x16& acc, const float2 
   }
   return s + __shfl_xor(s, 32);
 }
+// the same chain with {b1, w2} read from LDS as it goes (8 registers instead of 32: the 128-register GEMM epilogue)
+template <bool FAST>
+__device__ __forceinline__ float rowdot_block_t_lds(const f32x16& acc, const float2* __restrict__ src, int half) {
+  float s = 0.f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float2 c[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[r] = src[8 * g + 4 * half + r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float pre = acc[4 * g + r] + c[r].x;
+      s = fmaf(FAST ? fast_tanh(pre) : tanhf(pre), c[r].y, s);
+    }
+  }
+  return s + __shfl_xor(s, 32);
+}
 // {b1, w2} of the 16 hidden units a lane holds in a block (element e = 4 g + r <-> unit 8 g + 4 half + r), from the block's
 // 32 interleaved pairs in LDS; loaded ONCE per hidden block and reused for every token block of the wave
 __device__ __forceinline__ void rowdot_load_bw(float2 (&bw)[16], const float2* __restrict__ src, int half) {
