@@ -845,11 +845,12 @@ CompactPlan make_compact_plan(int64_t n_news, int S, int D, int A, int E, bool a
   p.off_q = att ? take(rows * D * 4) : 0;
   p.off_o = att ? take(rows * D * 4) : 0;
   p.off_t = take(rows * (size_t)n_ep * 4);
-  p.off_roff = take(((size_t)chunk + 1) * 8);
-  p.off_live = take(rows * 4);
-  p.off_kvs = take(rows * 4);
-  p.off_kvd = take(rows * 4);
-  p.off_cnt = take((size_t)((n_news + chunk - 1) / chunk) * 3 * 8);  // {live rows, K|V rows, bad-mask flag} per pass
+  const size_t passes = (size_t)((n_news + chunk - 1) / chunk);
+  p.off_roff = take(passes * ((size_t)chunk + 1) * 8);  // the row lists of EVERY pass (one compaction launch per call)
+  p.off_live = take(passes * rows * 4);
+  p.off_kvs = take(passes * rows * 4);
+  p.off_kvd = take(passes * rows * 4);
+  p.off_cnt = take(passes * 3 * 8);  // {live rows, K|V rows, bad-mask flag} per pass
   p.off_p = head ? take((size_t)n_news * D * 4) : 0;
   p.off_h = head ? take((size_t)n_news * E * 4) : 0;
   p.off_fw = att ? take((size_t)A * D * 4) : 0;
@@ -890,10 +891,10 @@ int32_t xnrs_text_encoder_fwd_compact(const float* x, const float* m, const int3
   float* qc = reinterpret_cast<float*>(w + p.off_q);
   float* oc = reinterpret_cast<float*>(w + p.off_o);
   float* tc = reinterpret_cast<float*>(w + p.off_t);
-  int64_t* roff = reinterpret_cast<int64_t*>(w + p.off_roff);
-  int32_t* live = reinterpret_cast<int32_t*>(w + p.off_live);
-  int32_t* kvs = reinterpret_cast<int32_t*>(w + p.off_kvs);
-  int32_t* kvd = reinterpret_cast<int32_t*>(w + p.off_kvd);
+  int64_t* roff0 = reinterpret_cast<int64_t*>(w + p.off_roff);
+  int32_t* live0 = reinterpret_cast<int32_t*>(w + p.off_live);
+  int32_t* kvs0 = reinterpret_cast<int32_t*>(w + p.off_kvs);
+  int32_t* kvd0 = reinterpret_cast<int32_t*>(w + p.off_kvd);
   int64_t* cnt0 = reinterpret_cast<int64_t*>(w + p.off_cnt);
   float* pb = reinterpret_cast<float*>(w + p.off_p);
   float* hb = reinterpret_cast<float*>(w + p.off_h);
@@ -918,11 +919,16 @@ int32_t xnrs_text_encoder_fwd_compact(const float* x, const float* m, const int3
   }
   if (att && !fold) return XNRS_EUNSUPPORTED;  // (the per-token out-projection order: use the host-compacted entry point)
   const int n_ep = (A + 31) / 32;
+  XNRS_TRY(launch_compact_rows(m, ids, n_news, p.chunk, S, roff0, live0, kvs0, kvd0, cnt0, stream));
   for (int64_t c0 = 0; c0 < n_news; c0 += p.chunk) {
     const int64_t nc = (n_news - c0 < p.chunk) ? (n_news - c0) : p.chunk;
     const int64_t rows = nc * S;  // worst case
-    int64_t* cnt = cnt0 + 3 * (c0 / p.chunk);
-    XNRS_TRY(launch_compact_rows(m, ids, c0, (int)nc, S, roff, live, kvs, kvd, cnt, stream));
+    const int64_t pass = c0 / p.chunk;
+    const int64_t* cnt = cnt0 + 3 * pass;
+    const int64_t* roff = roff0 + pass * (p.chunk + 1);
+    const int32_t* live = live0 + pass * p.chunk * S;
+    const int32_t* kvs = kvs0 + pass * p.chunk * S;
+    const int32_t* kvd = kvd0 + pass * p.chunk * S;
     const float* vals = x;           // what the pooler weights: compact O rows, or x rows through `live`
     const int32_t* val_ids = live;
     if (att) {

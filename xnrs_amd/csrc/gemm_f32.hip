@@ -109,8 +109,21 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmArgs a, i
   __shared__ __attribute__((aligned(16))) float As[NBUF][A_SZ];
   __shared__ __attribute__((aligned(16))) float Bs[NBUF][B_SZ];
 
+  // rows that exist: a.M, or -- MDEV -- the device scalar *a.m_dev (a.M was only the grid's worst case), kept in SGPRs.
+  // The tile walk below then runs over the row tiles that exist, and the workgroups past them leave at once: mapped over
+  // the launched grid instead, the live row tiles would all fall on the first XCDs (each XCD owns a contiguous range of
+  // the walk) -- measured: a pass with 25 % of its rows live took as long as a full one.
+  int64_t Mrun = a.M;
+  int nwg = gridDim.x;
+  if constexpr (MDEV) {
+    const int64_t md = *a.m_dev;
+    Mrun = ((int64_t)__builtin_amdgcn_readfirstlane((int)(md >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)md);
+    if (Mrun > a.M) Mrun = a.M;
+    m_tiles = (int)((Mrun + BM - 1) / BM);
+    nwg = m_tiles * n_tiles_seg * a.nseg;
+    if ((int)blockIdx.x >= nwg) return;  // workgroup-uniform, before any barrier
+  }
   // ---- XCD-aware tile order (bijective for any grid size); blockIdx.y = k slice
-  const int nwg = gridDim.x;
   const int bid = blockIdx.x;
   const int xcd = bid & 7;
   const int q = nwg >> 3, r = nwg & 7;
@@ -128,13 +141,6 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmArgs a, i
   const int nts = nt - seg * n_tiles_seg;
   const int64_t m0 = (int64_t)mt * BM;
   const int n0 = nts * BN;  // column inside the segment
-  // rows that exist: a.M, or -- MDEV -- the device scalar *a.m_dev (a.M was only the grid's worst case), kept in SGPRs
-  int64_t Mrun = a.M;
-  if constexpr (MDEV) {
-    const int64_t md = *a.m_dev;
-    Mrun = ((int64_t)__builtin_amdgcn_readfirstlane((int)(md >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)md);
-    if (m0 >= Mrun) return;  // workgroup-uniform, before any barrier
-  }
 
   // contraction indices are 32-bit in the kernel (the launcher refuses K >= 2^31): the k-tail tests and tile offsets of
   // the inner loop are then single VALU / SALU instructions instead of 64-bit compare-and-select pairs

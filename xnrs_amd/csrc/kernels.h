@@ -451,8 +451,9 @@ struct BatchArgs {
 hipError_t launch_gather_rows(const float* table, const int32_t* ids, float* out, int64_t n, int64_t row_floats,
                               hipStream_t stream);
 hipError_t launch_poison(float* y, int64_t n, const int64_t* flags, int n_flags, int flag_stride, hipStream_t stream);
-// live-row / kept-K|V-row lists + CSR offsets of one pass of news, built on the device (batch.hip)
-hipError_t launch_compact_rows(const float* mask, const int32_t* ids, int64_t news0, int cn, int S, int64_t* row_off,
+// live-row / kept-K|V-row lists + CSR offsets of every pass of `chunk` news, built on the device in one launch (batch.hip):
+// pass p writes row_off[p*(chunk+1) ..], the lists at [p*chunk*S ..], counts[3*p ..]
+hipError_t launch_compact_rows(const float* mask, const int32_t* ids, int64_t n_news, int64_t chunk, int S, int64_t* row_off,
                                int32_t* live_src, int32_t* kv_src, int32_t* kv_dst, int64_t* counts, hipStream_t stream);
 hipError_t launch_assemble_train(const BatchArgs& a, hipStream_t stream);
 hipError_t launch_assemble_eval(const BatchArgs& a, hipStream_t stream);
