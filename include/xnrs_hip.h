@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define XNRS_ABI_VERSION 3
+#define XNRS_ABI_VERSION 4
 
 #define XNRS_OK 0
 #define XNRS_EINVAL (-1)     /* bad shape / NULL pointer */
@@ -245,6 +245,31 @@ int32_t xnrs_seq_encoder_bwd_live(const float *x, const float *m, const int32_t 
                                   float *dx, const xnrs_mha_grads *g_att, const xnrs_additive_grads *g_pool,
                                   const xnrs_head_grads *g_head, const int32_t *live_rows,
                                   const int32_t *live_src_rows, int64_t n_live, void *ws, size_t ws_bytes, void *stream);
+
+/* Both row lists of the grad step in one argument (ABI 4).  live_* as above.  kv_rows (int32 [n_kv], optional, rides on
+ * the live-row path): the token rows -- masked ones included -- of the news that have at least one unmasked token, in
+ * order.  The keys and values of a news are read by that news' own queries only, and an all-masked news (an empty history
+ * slot, dataset.py:82-85) has no live query: its K and V rows reach neither the output nor a gradient, and its dK / dV
+ * rows are exactly zero.  With the list the K|V projection of the forward and the dWk / dWv products of the backward run
+ * over those rows only (K and V of the other rows are stored as zeros).  kv_src_rows: the same tokens' rows in x when
+ * ids != NULL.  Identical results up to summation order; a NULL list pointer = the plain entry points. */
+typedef struct {
+  const int32_t *live_rows, *live_src_rows;
+  int64_t n_live;
+  const int32_t *kv_rows, *kv_src_rows;
+  int64_t n_kv;
+} xnrs_row_lists;
+int32_t xnrs_seq_encoder_fwd_train_rows(const float *x, const float *m, const int32_t *ids, int64_t n_seq, int32_t L,
+                                        int32_t D, const xnrs_mha_params *att, int32_t pool_kind,
+                                        const xnrs_additive_params *pool, const xnrs_head_params *head, float *y,
+                                        float *a_out, float *hm, void *saved, size_t saved_bytes,
+                                        const xnrs_row_lists *rows, void *stream);
+int32_t xnrs_seq_encoder_bwd_rows(const float *x, const float *m, const int32_t *ids, int64_t n_seq, int32_t L, int32_t D,
+                                  const xnrs_mha_params *att, int32_t pool_kind, const xnrs_additive_params *pool,
+                                  const xnrs_head_params *head, const void *saved, size_t saved_bytes, const float *dy,
+                                  float *dx, const xnrs_mha_grads *g_att, const xnrs_additive_grads *g_pool,
+                                  const xnrs_head_grads *g_head, const xnrs_row_lists *rows, void *ws, size_t ws_bytes,
+                                  void *stream);
 
 /* autograd of nn.Linear (xnrs_linear_fwd): dx = dy.W (nullable), dw = dy^T.x, db = colsum(dy) (nullable).
  * gather_ids as in the forward (then dx must be NULL). */

@@ -386,11 +386,13 @@ def test_backward_over_live_rows_matches_dense_backward(with_ids):
     x = torch.from_numpy(rng.standard_normal((n_tab, S, D)).astype("float32"))
     m = torch.from_numpy((rng.random((n_tab, S)) < 0.55).astype("float32"))
     m[:5] = 0
+    m[torch.from_numpy(rng.random(n_tab) < 0.3)] = 0  # empty history slots: the K|V row list (xnrs_row_lists) leaves them out
     w = torch.from_numpy(rng.standard_normal((n_tab if not with_ids else 300, E)).astype("float32"))
     ids = torch.from_numpy(rng.integers(0, n_tab, size=(300,)).astype("int64")) if with_ids else None
 
-    def run(live):
+    def run(live, kv=True):
         AG.LIVE_ROWS = live
+        AG.KV_ROWS = kv
         try:
             enc.zero_grad(set_to_none=True)
             xd = x.to(DEV).requires_grad_(not with_ids)
@@ -403,17 +405,24 @@ def test_backward_over_live_rows_matches_dense_backward(with_ids):
             (y * w.to(DEV)).sum().backward()
         finally:
             AG.LIVE_ROWS = True
+            AG.KV_ROWS = True
         return y.detach(), {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None}, xd.grad
 
     y0, g0, dx0 = run(False)
+    before = AG.STATS["kv_row_forwards"]
     y1, g1, dx1 = run(True)
-    assert torch.equal(y0, y1) and g0.keys() == g1.keys()
+    assert AG.STATS["kv_row_forwards"] == before + 1  # the K|V list was in use
+    y2, g2, dx2 = run(True, kv=False)
+    assert AG.STATS["kv_row_forwards"] == before + 1
+    assert torch.equal(y0, y1) and torch.equal(y0, y2) and g0.keys() == g1.keys() == g2.keys()
     gmax = max(v.abs().max().item() for v in g0.values())
     for k in g0:
         scale = max(g0[k].abs().max().item(), 1e-3 * gmax)
         assert (g1[k] - g0[k]).abs().max().item() / scale <= 2e-5, k
+        assert (g2[k] - g0[k]).abs().max().item() / scale <= 2e-5, k
     if not with_ids:
         H.assert_close(dx1, dx0, 2e-5, "dx live vs dense")
+        H.assert_close(dx2, dx0, 2e-5, "dx live (dense K|V) vs dense")
         # and against torch autograd through the oracle
         osd = oracle_sd(sd)
         xo = x.clone().requires_grad_(True)

@@ -81,7 +81,14 @@ LIVE_ROWS = os.environ.get("XNRS_BWD_LIVE_ROWS", "1") != "0"
 LIVE_ROWS_MAX_FRACTION = 0.9
 LIVE_ROWS_MIN = 4096  # token rows from which the live-row path pays for its index bookkeeping (tests lower it)
 #: how many training forwards took the live-row path (tests assert that the branch they mean to cover really ran)
-STATS = {"live_row_forwards": 0}
+STATS = {"live_row_forwards": 0, "kv_row_forwards": 0}
+#: K|V projection and dWk / dWv over the token rows of the non-empty news only (rides on the live-row path, exact;
+#: include/xnrs_hip.h: xnrs_row_lists).  XNRS_KV_ROWS=0 turns it off.
+KV_ROWS = os.environ.get("XNRS_KV_ROWS", "1") != "0"
+
+
+def _addr(t):
+    return None if t is None else t.data_ptr()
 
 
 class _SeqEncode(torch.autograd.Function):
@@ -105,22 +112,39 @@ class _SeqEncode(torch.autograd.Function):
         # exp(e)*0), so the row-parallel products of an attention tower -- forward (query projection, output projection,
         # fc1) and backward -- run over the unmasked rows only (xnrs_seq_encoder_fwd_train_live / _bwd_live).  Index
         # bookkeeping with torch (one host sync for the count); skipped when few rows are masked.
-        live = live_src = None
-        n_live = 0
+        live = live_src = kv = kv_src = None
+        n_live = n_kv = 0
         if LIVE_ROWS and m is not None and cfg.n_heads > 0 and cfg.pool_kind == hip.POOL_ADDITIVE and n * L >= LIVE_ROWS_MIN:
-            lm = (m[ids.long()] if ids is not None else m).reshape(-1).ne(0)
-            rows_live = lm.nonzero().squeeze(1)
-            if rows_live.numel() <= LIVE_ROWS_MAX_FRACTION * n * L:
-                live, n_live = rows_live.to(torch.int32), rows_live.numel()
+            lm = (m[ids.long()] if ids is not None else m).reshape(n, L).ne(0)
+            news_live = lm.any(dim=1)
+            # ONE host read for both counts (unmasked token rows, non-empty news); the lists are then sized without a sync
+            n_live, n_news_live = (int(v) for v in torch.stack([lm.sum(), news_live.sum()]).tolist())
+            if n_live <= LIVE_ROWS_MAX_FRACTION * n * L:
+                rows_live = torch.nonzero_static(lm.reshape(-1), size=n_live).squeeze(1)
+                live = rows_live.to(torch.int32)
                 STATS["live_row_forwards"] += 1
+                src_news = ids.long() if ids is not None else None
                 if ids is not None:
                     seq = torch.div(rows_live, L, rounding_mode="floor")
-                    live_src = (ids.long()[seq] * L + (rows_live - seq * L)).to(torch.int32)
-        hip.check(l.xnrs_seq_encoder_fwd_train_live(hip.ptr(x), hip.ptr(m), hip.ptr(ids), n, L, D, _ref(ap), cfg.pool_kind,
+                    live_src = (src_news[seq] * L + (rows_live - seq * L)).to(torch.int32)
+                # the token rows of the non-empty news: K and V are projected (and their weight gradients summed) over
+                # these only -- nobody reads the keys of a news without a live query (include/xnrs_hip.h: xnrs_row_lists)
+                if KV_ROWS and n_news_live < n:
+                    news_idx = torch.nonzero_static(news_live, size=n_news_live).squeeze(1)
+                    tok = torch.arange(L, device=dev)
+                    kv = (news_idx[:, None] * L + tok[None, :]).reshape(-1).to(torch.int32)
+                    n_kv = n_news_live * L
+                    STATS["kv_row_forwards"] += 1
+                    if ids is not None:
+                        kv_src = (src_news[news_idx][:, None] * L + tok[None, :]).reshape(-1).to(torch.int32)
+        lists = None
+        if live is not None:
+            lists = hip.RowLists(_addr(live), _addr(live_src), n_live, _addr(kv), _addr(kv_src), n_kv)
+        hip.check(l.xnrs_seq_encoder_fwd_train_rows(hip.ptr(x), hip.ptr(m), hip.ptr(ids), n, L, D, _ref(ap), cfg.pool_kind,
                                                     _ref(pp), _ref(hp), hip.ptr(y), hip.ptr(a), hip.ptr(hm), hip.ptr(saved),
-                                                    nsaved, hip.ptr(live), hip.ptr(live_src), n_live, hip.stream_ptr(dev)),
-                  "xnrs_seq_encoder_fwd_train_live")
-        ctx.live, ctx.live_src, ctx.n_live = live, live_src, n_live
+                                                    nsaved, _ref(lists), hip.stream_ptr(dev)),
+                  "xnrs_seq_encoder_fwd_train_rows")
+        ctx.row_lists = (live, live_src, n_live, kv, kv_src, n_kv)
         ctx.fold = l.xnrs_train_fold_enabled()  # the saved blob is laid out by this decision (include/xnrs_hip.h)
         ctx.cfg = cfg
         ctx.nsaved = nsaved
@@ -167,11 +191,14 @@ class _SeqEncode(torch.autograd.Function):
                                    "activations were laid out for the other setting (reload the knobs outside a step)")
         nws = l.xnrs_seq_encoder_bwd_workspace_bytes(n, L, D, cfg.A, Eo, cfg.n_heads, cfg.pool_kind, int(cfg.has_head))
         ws = hip.workspace(dev, nws)
-        live, live_src, n_live = ctx.live, ctx.live_src, ctx.n_live  # the unmasked rows found by the forward
-        hip.check(l.xnrs_seq_encoder_bwd_live(hip.ptr(x), hip.ptr(m), hip.ptr(ids), n, L, D, _ref(ap), cfg.pool_kind, _ref(pp),
+        live, live_src, n_live, kv, kv_src, n_kv = ctx.row_lists  # the row lists built by the forward
+        lists = None
+        if live is not None:
+            lists = hip.RowLists(_addr(live), _addr(live_src), n_live, _addr(kv), _addr(kv_src), n_kv)
+        hip.check(l.xnrs_seq_encoder_bwd_rows(hip.ptr(x), hip.ptr(m), hip.ptr(ids), n, L, D, _ref(ap), cfg.pool_kind, _ref(pp),
                                               _ref(hp), hip.ptr(saved), ctx.nsaved, hip.ptr(dy), hip.ptr(dx), _ref(ga),
-                                              _ref(gp), _ref(gh), hip.ptr(live), hip.ptr(live_src), n_live, hip.ptr(ws), nws,
-                                              hip.stream_ptr(dev)), "xnrs_seq_encoder_bwd_live")
+                                              _ref(gp), _ref(gh), _ref(lists), hip.ptr(ws), nws,
+                                              hip.stream_ptr(dev)), "xnrs_seq_encoder_bwd_rows")
         return (None, dx, None, None, *grads)
 
 

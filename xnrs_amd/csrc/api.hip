@@ -232,7 +232,8 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
                    const xnrs_mha_params* att, bool pooled, int pool_kind, const xnrs_additive_params* pool,
                    const xnrs_head_params* head, float* y, float* a_out, float* hm, int64_t chunk, void* ws,
                    size_t ws_bytes, hipStream_t stream, bool train = false, const int32_t* live_rows = nullptr,
-                   const int32_t* live_src_rows = nullptr, int64_t n_live = 0) {
+                   const int32_t* live_src_rows = nullptr, int64_t n_live = 0, const int32_t* kv_rows = nullptr,
+                   const int32_t* kv_src_rows = nullptr, int64_t n_kv = 0) {
   if (n_seq == 0) return XNRS_OK;
   if (n_seq < 0 || L <= 0 || D <= 0 || !x || !y) return XNRS_EINVAL;
   if (att) {
@@ -274,6 +275,11 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
   const bool live = train && att && additive && m && live_rows && n_live >= 0 && n_live < n_seq * L &&
                     !(ids && !live_src_rows);
   const int32_t* lvx = live ? (ids ? live_src_rows : live_rows) : nullptr;  // rows of x (table rows with ids)
+  // ... and K|V over the token rows of the NON-EMPTY news only (kv_rows, optional, exact): the keys and values of a news
+  // are read by that news' own queries alone, and an all-masked news has no live query, so its K and V rows (zeroed
+  // here: its attention rows then come out as finite zeros) reach neither the output nor a gradient.
+  const bool kvl = live && kv_rows && n_kv >= 0 && n_kv < n_seq * L && !(ids && !kv_src_rows);
+  const int32_t* kvx = kvl ? (ids ? kv_src_rows : kv_rows) : nullptr;
 
   // Short sequences go through the fused kernel (below); everything else folds the out-projection behind the pooling.
   // The predicate covers EVERY precondition of the launch (shape, 16-byte aligned operands, 160 KB of dynamic LDS on the
@@ -421,15 +427,25 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
       g.K = D;
       g.act = XNRS_ACT_NONE;
       const int dk = D / att->n_heads;
-      if (live) {  // K|V of every row, Q of the live rows only (dead Q rows = 0)
-        ProfScope ps(0, 2.0 * rows * 2.0 * D * D + 2.0 * n_live * (double)D * D, stream);
+      if (live) {  // K|V of every row (kvl: of the rows of the non-empty news), Q of the live rows only (dead rows = 0)
+        ProfScope ps(0, 2.0 * (kvl ? n_kv : rows) * 2.0 * D * D + 2.0 * n_live * (double)D * D, stream);
         g.W[0] = att->wk; g.W[1] = att->wv; g.W[2] = nullptr;
         g.Wp[0] = pk; g.Wp[1] = pv; g.Wp[2] = nullptr;
         g.bias[0] = att->bk; g.bias[1] = att->bv; g.bias[2] = nullptr;
         g.nseg = 2;
         g.C = qkv + D;
-        XNRS_TRY(launch_gemm_f32(g, stream));
-        XNRS_TRY(launch_zero_cols(qkv, 3 * (int64_t)D, D, rows, stream));
+        if (kvl) {
+          XNRS_TRY(launch_zero_cols(qkv, 3 * (int64_t)D, 3 * D, rows, stream));
+          g.gather_ids = kvx;
+          g.gather_S = 1;
+          g.c_scatter = 1;
+          g.c_scatter_ids = kv_rows;
+          g.M = n_kv;
+          if (n_kv > 0) XNRS_TRY(launch_gemm_f32(g, stream));
+        } else {
+          XNRS_TRY(launch_gemm_f32(g, stream));
+          XNRS_TRY(launch_zero_cols(qkv, 3 * (int64_t)D, D, rows, stream));
+        }
         if (n_live > 0) {
           GemmArgs q = gemm1(cx, lvx, 1, D, att->wq, att->bq, qkv, 3 * (int64_t)D, n_live, D, D, XNRS_ACT_NONE, pq);
           q.c_scatter = 1;
@@ -463,6 +479,7 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
       ma.dropout_p = att->dropout_p;
       ma.seed = att->seed + (uint64_t)c0 * 0x9E3779B97F4A7C15ull;
       ma.stats = stats;
+      ma.skip_dead = live ? 1 : 0;  // an all-masked news: zeros instead of attention over keys nobody weights (kernels.h)
       {
         ProfScope ps(1, 4.0 * rows * (double)L * D, stream);
         XNRS_TRY(launch_mha_core(ma, stream));
@@ -1301,10 +1318,27 @@ int32_t xnrs_seq_encoder_fwd_train_live(const float* x, const float* m, const in
                                         const xnrs_head_params* head, float* y, float* a_out, float* hm, void* saved,
                                         size_t saved_bytes, const int32_t* live_rows, const int32_t* live_src_rows,
                                         int64_t n_live, void* stream) {
+  xnrs_row_lists r{};
+  r.live_rows = live_rows;
+  r.live_src_rows = live_src_rows;
+  r.n_live = n_live;
+  return xnrs_seq_encoder_fwd_train_rows(x, m, ids, n_seq, L, D, att, pool_kind, pool, head, y, a_out, hm, saved, saved_bytes,
+                                         live_rows ? &r : nullptr, stream);
+}
+
+int32_t xnrs_seq_encoder_fwd_train_rows(const float* x, const float* m, const int32_t* ids, int64_t n_seq, int32_t L, int32_t D,
+                                        const xnrs_mha_params* att, int32_t pool_kind, const xnrs_additive_params* pool,
+                                        const xnrs_head_params* head, float* y, float* a_out, float* hm, void* saved,
+                                        size_t saved_bytes, const xnrs_row_lists* r, void* stream) {
   const bool pooled = pool_kind != XNRS_POOL_NONE;
-  if (live_rows && ids && !live_src_rows) return XNRS_EINVAL;  // a gathered table needs the table rows of the live tokens
+  xnrs_row_lists none{};
+  if (!r) r = &none;
+  if (r->kv_rows && !r->live_rows) return XNRS_EINVAL;  // the K|V list rides on the live-row path
+  // a gathered table needs the table rows of the listed tokens
+  if (ids && ((r->live_rows && !r->live_src_rows) || (r->kv_rows && !r->kv_src_rows))) return XNRS_EINVAL;
   return seq_encode(x, m, ids, n_seq, L, D, att, pooled, pool_kind, pool, pooled ? head : nullptr, y, a_out, hm, 0, saved,
-                    saved_bytes, (hipStream_t)stream, true, live_rows, live_src_rows, n_live);
+                    saved_bytes, (hipStream_t)stream, true, r->live_rows, r->live_src_rows, r->n_live, r->kv_rows,
+                    r->kv_src_rows, r->n_kv);
 }
 
 size_t xnrs_seq_encoder_bwd_workspace_bytes(int64_t n_seq, int32_t L, int32_t D, int32_t A, int32_t E, int32_t n_heads,
@@ -1328,6 +1362,27 @@ int32_t xnrs_seq_encoder_bwd_live(const float* x, const float* m, const int32_t*
                                   float* dx, const xnrs_mha_grads* g_att, const xnrs_additive_grads* g_pool,
                                   const xnrs_head_grads* g_head, const int32_t* live_rows, const int32_t* live_src_rows,
                                   int64_t n_live, void* ws, size_t ws_bytes, void* stream_) {
+  xnrs_row_lists r{};
+  r.live_rows = live_rows;
+  r.live_src_rows = live_src_rows;
+  r.n_live = n_live;
+  return xnrs_seq_encoder_bwd_rows(x, m, ids, n_seq, L, D, att, pool_kind, pool, head, saved, saved_bytes, dy, dx, g_att, g_pool,
+                                   g_head, live_rows ? &r : nullptr, ws, ws_bytes, stream_);
+}
+
+int32_t xnrs_seq_encoder_bwd_rows(const float* x, const float* m, const int32_t* ids, int64_t n_seq, int32_t L, int32_t D,
+                                  const xnrs_mha_params* att, int32_t pool_kind, const xnrs_additive_params* pool,
+                                  const xnrs_head_params* head, const void* saved, size_t saved_bytes, const float* dy,
+                                  float* dx, const xnrs_mha_grads* g_att, const xnrs_additive_grads* g_pool,
+                                  const xnrs_head_grads* g_head, const xnrs_row_lists* rl, void* ws, size_t ws_bytes,
+                                  void* stream_) {
+  xnrs_row_lists none{};
+  if (!rl) rl = &none;
+  const int32_t* live_rows = rl->live_rows;
+  const int32_t* live_src_rows = rl->live_src_rows;
+  const int64_t n_live = rl->n_live;
+  if (rl->kv_rows && !live_rows) return XNRS_EINVAL;
+  if (ids && rl->kv_rows && !rl->kv_src_rows) return XNRS_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   if (n_seq == 0) return XNRS_OK;
   if (n_seq < 0 || L <= 0 || D <= 0 || !x || !dy) return XNRS_EINVAL;
@@ -1374,6 +1429,11 @@ int32_t xnrs_seq_encoder_bwd_live(const float* x, const float* m, const int32_t*
   const int32_t* lv = live ? live_rows : nullptr;
   const int32_t* lvx = live ? (live_src_rows ? live_src_rows : live_rows) : nullptr;
   if (live_rows && ids && !live_src_rows) return XNRS_EINVAL;  // a gathered table needs the table rows of the live tokens
+  // K / V gradients over the token rows of the non-empty news (the forward's kv list): an all-masked news has no live query,
+  // so its dK and dV rows are exactly zero
+  const bool kvl = live && rl->kv_rows && rl->n_kv >= 0 && rl->n_kv < rows;
+  const int32_t* kvr = kvl ? rl->kv_rows : nullptr;
+  const int32_t* kvx = kvl ? (rl->kv_src_rows ? rl->kv_src_rows : rl->kv_rows) : nullptr;
   const bool fold = att && pooled && additive && fold_wanted(knobs().fold_train);  // = the forward's decision
 
   // gradient w.r.t. the sequence rows that fed the pooler (att output, or x itself)
@@ -1531,6 +1591,10 @@ int32_t xnrs_seq_encoder_bwd_live(const float* x, const float* m, const int32_t*
   mb.dropout_p = att->dropout_p;
   mb.seed = att->seed;
   mb.masked_do_is_zero = (pooled && m) ? 1 : 0;  // both poolers give masked rows a zero gradient
+  // an all-masked news has dQ = dK = dV = 0: written without reading (1), or -- when every consumer goes through the row
+  // lists and no input gradient is asked for -- not even written (2)
+  const bool lists_only = kvl && !dx && g_att && g_att->wq && g_att->wk && g_att->wv;  // (a bias-only gradient sums dense rows)
+  mb.dead_seq_mode = live ? (lists_only ? 2 : 1) : 0;
   {
     ProfScope ps(9, 10.0 * rows * (double)L * D, stream);  // S, dP, dV, dK, dQ: five S x S x d_k products per head
     XNRS_TRY(launch_mha_bwd(mb, stream));
@@ -1542,8 +1606,10 @@ int32_t xnrs_seq_encoder_bwd_live(const float* x, const float* m, const int32_t*
   for (int s3 = 0; s3 < 3; ++s3) {
     const float* dpart = dqkv + (int64_t)s3 * D;
     if (gw[s3]) {
-      if (s3 == 0 && live)  // dQ is zero on masked rows; dK / dV are not (padded tokens are keys)
+      if (s3 == 0 && live)  // dQ is zero on masked rows; dK / dV are not (padded tokens are keys) ...
         XNRS_TRY(gemm_dw(dpart, 3 * (int64_t)D, x, nullptr, 0, D, gw[s3], rows, D, D, slabs, stream, lv, lvx, n_live, gb[s3], csum));
+      else if (s3 > 0 && kvl)  // ... except on the rows of an all-masked news
+        XNRS_TRY(gemm_dw(dpart, 3 * (int64_t)D, x, nullptr, 0, D, gw[s3], rows, D, D, slabs, stream, kvr, kvx, rl->n_kv, gb[s3], csum));
       else
         XNRS_TRY(gemm_dw(dpart, 3 * (int64_t)D, x, ids, L, D, gw[s3], rows, D, D, slabs, stream, nullptr, nullptr, 0, gb[s3], csum));
     } else if (gb[s3]) {

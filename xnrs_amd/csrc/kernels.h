@@ -155,6 +155,11 @@ struct MhaCoreArgs {
   // (mask is ignored), K and V keep the padded [n_seq*S] addressing.  LDS-staged kernel only (S, d_k <= 64).
   const int64_t* q_off;
   int64_t ldq;
+  // 1 (optional, with mask; pair kernel only, ignored elsewhere): a sequence whose query rows are ALL masked is not
+  // computed -- its output rows are written as zeros and its statistics as those of masked rows {-1e9, S}.  For callers
+  // whose consumers give masked rows a zero weight (the training forward over live rows, api.hip): such rows reach
+  // neither the output nor a gradient, and with K = V = 0 (xnrs_row_lists) zeros are what the kernel would compute.
+  int32_t skip_dead;
 };
 hipError_t launch_mha_core(const MhaCoreArgs& a, hipStream_t stream);
 
@@ -183,6 +188,10 @@ struct MhaBwdArgs {
   uint64_t seed;
   int32_t masked_do_is_zero;  // 1: the caller guarantees d_o == 0 on rows with mask == 0 (a masked pooler sits on top):
                               // query tiles whose 16 rows are all masked are skipped (their dQ rows are written as 0)
+  // with masked_do_is_zero, fused kernel: a sequence whose query rows are ALL masked has dQ = dK = dV = 0 exactly.
+  // 1: its workgroups write those zeros without reading anything; 2: they write nothing (the caller reads the gradient
+  // rows of such sequences nowhere: live-row dWq, kv-row dWk / dWv, no input gradient).  0: no early exit.
+  int32_t dead_seq_mode;
 };
 hipError_t launch_mha_bwd(const MhaBwdArgs& a, hipStream_t stream);
 

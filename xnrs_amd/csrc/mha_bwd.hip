@@ -321,6 +321,25 @@ __global__ __launch_bounds__(256) void mha_bwd_fused_kernel(MhaBwdArgs a) {
   const int hoff = hd * dk;
   const int QT = (S + 15) >> 4;  // query tiles = key tiles
   const bool active = wave < QT;
+  if (a.dead_seq_mode && a.masked_do_is_zero && a.mask) {  // (kernel arguments: uniform)
+    const int64_t mr = a.mask_gather_ids ? (int64_t)a.mask_gather_ids[seq] * S : row0;
+    if (!__syncthreads_or(tid < S && a.mask[mr + tid] != 0.f)) {
+      // every query row masked: dO = 0 and dS = 0 on every row, so dQ = dK = dV = 0 -- written without reading anything
+      // (mode 1), or left alone when the caller reads these rows nowhere (mode 2)
+      if (a.dead_seq_mode == 1) {
+        for (int idx = tid; idx < S * (NFB * 4); idx += 256) {
+          const int row = idx / (NFB * 4), f0 = (idx - row * (NFB * 4)) * 4;
+          if (f0 < dk) {
+            const int64_t off = (row0 + row) * a.ldd + hoff + f0;
+            *reinterpret_cast<f32x4*>(a.dq + off) = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(a.dk + off) = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(a.dv + off) = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+      }
+      return;
+    }
+  }
 
   // ---- stage Q and dO of this head (rows >= S and features >= d_k as zeros); delta = rowsum(dO * O) of the head is
   // taken on the way (a separate pass over dO and O -- mha_delta_kernel -- read 590 MB per 96 000-row encode for it):

@@ -510,7 +510,7 @@ __global__ __launch_bounds__(256, (KTM * NFB <= 9 ? 8 : 5)) void mha_core_pair_k
   // range of pairs its workgroups number (neighbouring sequences are neighbours in memory too: 1.5 % faster than dealing
   // them round-robin); unpadded queries: the work follows the masks, sequences are dealt round-robin (kernels.h xcd_pair).
   int pair;
-  if (a.q_off) {
+  if (a.q_off || a.skip_dead) {  // (skip_dead: the empty history slots of a user are neighbours -- deal them out too)
     pair = (int)xcd_pair(blockIdx.x, gridDim.x, a.n_heads);
   } else {
     const int L = blockIdx.x, W = gridDim.x, x = L & 7, per = W >> 3, rm = W & 7;
@@ -545,6 +545,24 @@ __global__ __launch_bounds__(256, (KTM * NFB <= 9 ? 8 : 5)) void mha_core_pair_k
   if (a.mask && !a.q_off && qvalid) {
     const int64_t mrow = a.mask_gather_ids ? (int64_t)a.mask_gather_ids[seq] * S : (int64_t)seq * S;
     mq = a.mask[mrow + query];
+  }
+  if (a.skip_dead && a.mask && !a.q_off) {  // (kernel argument: uniform)
+    if (!__syncthreads_or(qvalid && mq != 0.f)) {  // every query row of this sequence is masked: zeros, nothing read
+      if (qvalid) {
+        float* orow = a.out + (q0 + query) * a.ldo + hd * dk;
+#pragma unroll
+        for (int dt = 0; dt < NFB; ++dt) {
+          const int dv0 = dt * 16 + 4 * g;
+          if (dv0 < dk) *reinterpret_cast<f32x4*>(orow + dv0) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (a.stats && g == 0) {
+          float* sp = a.stats + (((int64_t)seq * a.n_heads + hd) * (int64_t)S + query) * 2;
+          sp[0] = -1e9f;
+          sp[1] = (float)S;
+        }
+      }
+      return;
+    }
   }
 
   // ---- staging.  K: thread = (chunk ch of the row, key slot ks), keys ks, ks + KP, ...; one ds_write_b128 per chunk.
