@@ -435,7 +435,7 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
         g.nseg = 2;
         g.C = qkv + D;
         if (kvl) {
-          XNRS_TRY(launch_zero_cols(qkv, 3 * (int64_t)D, 3 * D, rows, stream));
+          XNRS_TRY(launch_zero_dead_qkv(qkv, cm, cids, nc, L, D, stream));
           g.gather_ids = kvx;
           g.gather_S = 1;
           g.c_scatter = 1;

@@ -654,6 +654,34 @@ hipError_t launch_zero_cols(float* p, int64_t ld, int width, int64_t rows, hipSt
   return hipGetLastError();
 }
 
+// The rows of a [n_seq*L, 3D] Q|K|V image that the live-row / kv-row projections (api.hip, xnrs_row_lists) leave unwritten,
+// zeroed by the mask itself (fp32 [.., L], optionally through news ids): the Q columns of every masked token row, and the
+// K|V columns of every row of an all-masked sequence.  One workgroup per sequence; writes 0.37 instead of 0.74 GB at the
+// grad step's 80 000 x 2304 image (zero_cols over the whole image: 0.14 ms per encode).
+__global__ __launch_bounds__(256) void zero_dead_qkv_kernel(float* qkv, const float* __restrict__ mask,
+                                                            const int32_t* __restrict__ ids, int L, int D4) {
+  const int64_t seq = blockIdx.x;
+  const float* mp = mask + (ids ? (int64_t)ids[seq] : seq) * L;
+  int any = 0;
+  for (int s = threadIdx.x; s < L; s += 256) any |= mp[s] != 0.f ? 1 : 0;
+  const bool empty = !__syncthreads_or(any);
+  const int w4 = empty ? 3 * D4 : D4;  // all-masked sequence: Q, K and V; otherwise the Q columns of its masked rows
+  f32x4* base = reinterpret_cast<f32x4*>(qkv) + seq * L * (int64_t)(3 * D4);
+  for (int s = 0; s < L; ++s) {
+    if (!empty && mp[s] != 0.f) continue;  // (uniform)
+    f32x4* row = base + (int64_t)s * (3 * D4);
+    for (int c = threadIdx.x; c < w4; c += 256) __builtin_nontemporal_store(f32x4{0.f, 0.f, 0.f, 0.f}, row + c);
+  }
+}
+
+hipError_t launch_zero_dead_qkv(float* qkv, const float* mask, const int32_t* ids, int64_t n_seq, int L, int D, hipStream_t stream) {
+  if (n_seq <= 0) return hipSuccess;
+  if (D % 4 != 0 || (reinterpret_cast<uintptr_t>(qkv) & 15) != 0 || n_seq > 0x7fffffffLL || !mask)
+    return launch_zero_cols(qkv, 3 * (int64_t)D, 3 * D, n_seq * L, stream);
+  hipLaunchKernelGGL(zero_dead_qkv_kernel, dim3((unsigned)n_seq), dim3(256), 0, stream, qkv, mask, ids, L, D / 4);
+  return hipGetLastError();
+}
+
 hipError_t launch_transpose(const float* W, float* Wt, int rows, int cols, hipStream_t stream) {
   if (rows <= 0 || cols <= 0) return hipSuccess;
   hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32)), dim3(256), 0, stream, W,

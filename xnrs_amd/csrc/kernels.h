@@ -108,6 +108,8 @@ struct GemmArgs {
 };
 // zero a [rows, width] column block of a row-major image of pitch ld (floats)
 hipError_t launch_zero_cols(float* p, int64_t ld, int width, int64_t rows, hipStream_t stream);
+// [n_seq*L, 3D] Q|K|V image: zero the Q columns of the masked token rows and all columns of the all-masked sequences
+hipError_t launch_zero_dead_qkv(float* qkv, const float* mask, const int32_t* ids, int64_t n_seq, int L, int D, hipStream_t stream);
 // Wt[c][r] = W[r][c] for a small row-major matrix W[rows][cols] (weights: a few MB)
 hipError_t launch_transpose(const float* W, float* Wt, int rows, int cols, hipStream_t stream);
 int gemm_pick_splits(int64_t M, int64_t N, int64_t K, bool dw_kernel = false);
