@@ -73,7 +73,7 @@ if gather_tag:
 
     def gcounter(passname, name):
         cc = glob.glob(os.path.join(gsrc, f"uniform_pmc_{passname}", "**", "*counter_collection.csv"), recursive=True)
-        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(cc[0])) if r["Counter_Name"] == name and "gather_rows" in r["Kernel_Name"]
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(cc[0])) if r["Counter_Name"] == name and "gather_rows_kernel<true>" in r["Kernel_Name"]
                 and int(r["Grid_Size"]) > 1000000] if cc else []
         return sum(vals) / len(vals) if vals else None
     gf, gw = gcounter("fetch", "FETCH_SIZE"), gcounter("write", "WRITE_SIZE")
