@@ -217,8 +217,9 @@ int32_t xnrs_seq_encoder_fwd_train(const float *x, const float *m, const int32_t
  * live_rows / live_src_rows / n_live as in xnrs_seq_encoder_bwd_live below, the query projection, the output projection
  * and fc1 run over the unmasked token rows in place and the masked rows of Q, Y and T are stored as zeros (a masked
  * row's pooling weight is exp(e) * 0: nothing downstream, forward or backward, depends on its values; K and V stay
- * dense because the reference masks query rows only, layers.py:142-144).  Used only with attention + additive pooling
- * + a mask; live_rows == NULL = xnrs_seq_encoder_fwd_train. */
+ * dense because the reference masks query rows only, layers.py:142-144).  Used with additive pooling + a mask: with an
+ * attention tower as described; without one (StandardRec, NAML's views) fc1 runs over the live rows of x and T of the
+ * masked rows is zero.  live_rows == NULL = xnrs_seq_encoder_fwd_train. */
 int32_t xnrs_seq_encoder_fwd_train_live(const float *x, const float *m, const int32_t *ids, int64_t n_seq, int32_t L,
                                         int32_t D, const xnrs_mha_params *att, int32_t pool_kind,
                                         const xnrs_additive_params *pool, const xnrs_head_params *head, float *y,
@@ -237,8 +238,8 @@ int32_t xnrs_seq_encoder_bwd(const float *x, const float *m, const int32_t *ids,
  * exactly zero; with live_rows (int32 [n_live]: indices of the unmasked rows in the padded [n_seq*L] row space, in
  * order) the row-parallel products of the attention tower -- fc1, output projection, Q projection -- run over those
  * rows in place; K / V gradients stay dense (padded tokens are keys, layers.py:142-144).  live_src_rows: the rows of
- * the live tokens in x when ids != NULL (table rows), NULL otherwise.  Used only with attention + additive pooling
- * + a mask; ignored (= xnrs_seq_encoder_bwd) otherwise. */
+ * the live tokens in x when ids != NULL (table rows), NULL otherwise.  Used with additive pooling + a mask (without an
+ * attention tower: dW1 and the input gradient's fc1 term over the live rows); ignored (= xnrs_seq_encoder_bwd) otherwise. */
 int32_t xnrs_seq_encoder_bwd_live(const float *x, const float *m, const int32_t *ids, int64_t n_seq, int32_t L, int32_t D,
                                   const xnrs_mha_params *att, int32_t pool_kind, const xnrs_additive_params *pool,
                                   const xnrs_head_params *head, const void *saved, size_t saved_bytes, const float *dy,

@@ -372,15 +372,17 @@ def test_skip_empty_gradients_match_dense():
         assert (g1[k] - ref).abs().max().item() / scale <= 1e-4, k
 
 
+@pytest.mark.parametrize("tower", ["attention", "additive_only"])
 @pytest.mark.parametrize("with_ids", [False, True])
-def test_backward_over_live_rows_matches_dense_backward(with_ids):
+def test_backward_over_live_rows_matches_dense_backward(with_ids, tower):
     """xnrs_seq_encoder_bwd_live (the row-parallel backward products over the unmasked token rows only) against the
     dense backward and against oracle autograd: parameter gradients of a TextEncoder with attention, masks with
     holes and fully masked news, with and without the id-gather (table) path, and the input gradient."""
     from xnrs_amd import autograd as AG
     S, D, h, E = 24, 64, 4, 32
+    att = layers.MultiHeadAttention(h, D) if tower == "attention" else None  # (StandardRec / NAML views: fc1 over live rows)
     enc, sd = load(news_encoding.TextEncoder(pooler=layers.AdditiveAttention(D, 48), p_dropout=0.0, out_features=E,
-                                             in_features=D, att=layers.MultiHeadAttention(h, D)), 171)
+                                             in_features=D, att=att), 171)
     rng = synth.rng_for(172)
     n_tab = 260
     x = torch.from_numpy(rng.standard_normal((n_tab, S, D)).astype("float32"))
@@ -411,9 +413,9 @@ def test_backward_over_live_rows_matches_dense_backward(with_ids):
     y0, g0, dx0 = run(False)
     before = AG.STATS["kv_row_forwards"]
     y1, g1, dx1 = run(True)
-    assert AG.STATS["kv_row_forwards"] == before + 1  # the K|V list was in use
+    assert AG.STATS["kv_row_forwards"] == before + (1 if att is not None else 0)  # the K|V list was in use
     y2, g2, dx2 = run(True, kv=False)
-    assert AG.STATS["kv_row_forwards"] == before + 1
+    assert AG.STATS["kv_row_forwards"] == before + (1 if att is not None else 0)
     assert torch.equal(y0, y1) and torch.equal(y0, y2) and g0.keys() == g1.keys() == g2.keys()
     gmax = max(v.abs().max().item() for v in g0.values())
     for k in g0:
@@ -429,7 +431,7 @@ def test_backward_over_live_rows_matches_dense_backward(with_ids):
         yo, _ = O.text_encoder(xo.unsqueeze(0), m.reshape(1, n_tab, S, 1), osd, h)
         (yo[0] * w).sum().backward()
         H.assert_close(dx1, xo.grad, GTOL, "dx vs oracle")
-        assert check_param_grads(enc, osd) >= 12
+        assert check_param_grads(enc, osd) >= (12 if att is not None else 6)
 
 
 @pytest.mark.parametrize("D", [96, 448])

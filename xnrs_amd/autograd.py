@@ -114,7 +114,7 @@ class _SeqEncode(torch.autograd.Function):
         # bookkeeping with torch (one host sync for the count); skipped when few rows are masked.
         live = live_src = kv = kv_src = None
         n_live = n_kv = 0
-        if LIVE_ROWS and m is not None and cfg.n_heads > 0 and cfg.pool_kind == hip.POOL_ADDITIVE and n * L >= LIVE_ROWS_MIN:
+        if LIVE_ROWS and m is not None and cfg.pool_kind == hip.POOL_ADDITIVE and n * L >= LIVE_ROWS_MIN:
             lm = (m[ids.long()] if ids is not None else m).reshape(n, L).ne(0)
             news_live = lm.any(dim=1)
             # ONE host read for both counts (unmasked token rows, non-empty news); the lists are then sized without a sync
@@ -129,7 +129,7 @@ class _SeqEncode(torch.autograd.Function):
                     live_src = (src_news[seq] * L + (rows_live - seq * L)).to(torch.int32)
                 # the token rows of the non-empty news: K and V are projected (and their weight gradients summed) over
                 # these only -- nobody reads the keys of a news without a live query (include/xnrs_hip.h: xnrs_row_lists)
-                if KV_ROWS and n_news_live < n:
+                if KV_ROWS and cfg.n_heads > 0 and n_news_live < n:
                     news_idx = torch.nonzero_static(news_live, size=n_news_live).squeeze(1)
                     tok = torch.arange(L, device=dev)
                     kv = (news_idx[:, None] * L + tok[None, :]).reshape(-1).to(torch.int32)

@@ -272,7 +272,9 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
   // gathered, C rows scattered through the same list); the dead rows of Q, Y and T are ZEROED first, which keeps every
   // later consumer -- attention core, pooling, and the backward kernels that read the saved activations -- finite and
   // exactly as if the rows had been computed and then multiplied by the zero weight.
-  const bool live = train && att && additive && m && live_rows && n_live >= 0 && n_live < n_seq * L &&
+  // An attention-FREE additive tower (StandardRec, NAML's views) takes the same list for its one row-parallel product:
+  // fc1 runs over the live token rows of x, T of the masked rows is zero.
+  const bool live = train && additive && m && live_rows && n_live >= 0 && n_live < n_seq * L &&
                     !(ids && !live_src_rows);
   const int32_t* lvx = live ? (ids ? live_src_rows : live_rows) : nullptr;  // rows of x (table rows with ids)
   // ... and K|V over the token rows of the NON-EMPTY news only (kv_rows, optional, exact): the keys and values of a news
@@ -508,12 +510,13 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
     float* pooled_dst = (head ? pb : y) + c0 * (int64_t)D;
     float* hm_dst = hm ? hm + c0 : nullptr;
     if (additive) {
-      if (live) {  // (live implies att: seq is the dense attention output, no id gather left)
+      if (live) {  // with attention seq is the dense attention output; without, the rows of x (table rows with ids: lvx)
         ProfScope ps(3, 2.0 * n_live * (double)D * A, stream);
         XNRS_TRY(hipMemsetAsync(t, 0, (size_t)rows * A * sizeof(float), stream));
         if (n_live > 0) {
-          GemmArgs fg = gemm1(seq, live_rows, 1, D, fc1_w, fc1_b, t, A, n_live, A, D, XNRS_ACT_TANH, p1);
+          GemmArgs fg = gemm1(seq, att ? live_rows : lvx, 1, D, fc1_w, fc1_b, t, A, n_live, A, D, XNRS_ACT_TANH, p1);
           fg.c_scatter = 1;
+          fg.c_scatter_ids = live_rows;
           XNRS_TRY(launch_gemm_f32(fg, stream));
         }
       } else {
@@ -1425,7 +1428,7 @@ int32_t xnrs_seq_encoder_bwd_rows(const float* x, const float* m, const int32_t*
   // Live rows (optional): the unmasked token rows.  A masked row has pooling weight 0, so every gradient that passes
   // through it is exactly zero (dy_i = a_i dp = 0, dpre_i = 0, dO_i = 0, dS_i = 0): the row-parallel GEMMs of the
   // attention tower run over the live rows only, in place.  K and V gradients stay dense (padded rows are keys).
-  const bool live = live_rows && att && pooled && additive && m && n_live >= 0 && n_live < rows;
+  const bool live = live_rows && pooled && additive && m && n_live >= 0 && n_live < rows;
   const int32_t* lv = live ? live_rows : nullptr;
   const int32_t* lvx = live ? (live_src_rows ? live_src_rows : live_rows) : nullptr;
   if (live_rows && ids && !live_src_rows) return XNRS_EINVAL;  // a gathered table needs the table rows of the live tokens
@@ -1542,8 +1545,10 @@ int32_t xnrs_seq_encoder_bwd_rows(const float* x, const float* m, const int32_t*
       XNRS_TRY(launch_additive_pool_bwd(pa, stream));
       if (g_pool && g_pool->w2) XNRS_TRY(launch_colsum(t, A, de, rows, A, g_pool->w2, csum, stream));
       if (g_pool && g_pool->b2) XNRS_TRY(launch_colsum(de, 1, nullptr, rows, 1, g_pool->b2, csum, stream));
-      if (g_pool && g_pool->w1)  // live => att: seq = yatt
-        XNRS_TRY(gemm_dw(dpre, A, seq, seq_ids, L, D, g_pool->w1, rows, A, D, slabs, stream, lv, lv, n_live, g_pool->b1, csum));
+      if (g_pool && g_pool->w1 && live)  // rows of dpre through lv; rows of seq through lv (yatt) or lvx (x / table rows)
+        XNRS_TRY(gemm_dw(dpre, A, seq, nullptr, 0, D, g_pool->w1, rows, A, D, slabs, stream, lv, att ? lv : lvx, n_live, g_pool->b1, csum));
+      else if (g_pool && g_pool->w1)
+        XNRS_TRY(gemm_dw(dpre, A, seq, seq_ids, L, D, g_pool->w1, rows, A, D, slabs, stream, nullptr, nullptr, 0, g_pool->b1, csum));
       else if (g_pool && g_pool->b1) XNRS_TRY(launch_colsum(dpre, A, nullptr, rows, A, g_pool->b1, csum, stream));
       if (need_dseq)
         XNRS_TRY(gemm_dx(dpre, A, pool->w1, dseq_dst, D, rows, A, D, nullptr, 0, 0, /*accumulate*/ 1, stream, wt, lv, n_live));
