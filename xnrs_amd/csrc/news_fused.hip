@@ -51,6 +51,18 @@ constexpr int NF_TY = 5;      // out-projection: tiles per wave, 4 feature waves
 constexpr int NF_TA = 2;      // fc1: tiles per wave, 8 waves  (A <= 256)
 constexpr int NF_FRAG = 256;  // floats of one (k step, tile) weight fragment: 64 lanes x 4
 constexpr int NF_THREADS = 512;
+// Column swizzle of both LDS row images: element (row, col) lives at row * L + (col ^ NF_SWZ(row)), bit 2 of the column
+// flipped on rows whose bit 2 is set.  Row strides are 8 mod 16 floats, which makes the row-fragment ds_read_b128s
+// conflict-free under the hardware's lane groups but leaves the accumulator ds_write_b128s (8 contiguous lanes = 8 token
+// rows at one feature chunk, banks mod 32) on 4 of their 8 slots -- no plain stride serves both (enumerated); with the
+// flip rows r and r + 4 of a store group land 16 bytes apart and the reads stay clean (brute-forced against the lane
+// groups of MI355X_MICROARCH.md, LDS).  The d_k % 16 tail columns go from 4-way to 2-way; the scalar gathers of V^T keep
+// their 2-way conflict (rows 4 apart are 32 banks apart whatever bit 2 does).  -DNF_SWZ_OFF: the plain layout.
+#ifdef NF_SWZ_OFF
+#define NF_SWZ(row) 0
+#else
+#define NF_SWZ(row) ((((row) >> 2) & 1) << 2)
+#endif
 
 template <int N>
 using IC = std::integral_constant<int, N>;
@@ -249,7 +261,7 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
       int64_t news = news0 + nw;
       if (news >= a.n_seq) news = a.n_seq - 1;
       const int64_t src = a.ids ? (int64_t)a.ids[news] : news;
-      *reinterpret_cast<f32x4*>(&r1[row * LY + 4 * ch]) =
+      *reinterpret_cast<f32x4*>(&r1[row * LY + ((4 * ch) ^ NF_SWZ(row))]) =
           __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.x + (src * S + s) * (int64_t)D + 4 * ch));
     }
   }
@@ -257,16 +269,17 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
   // ---- this lane's token row in each row tile: news nw = rt >> 1 owns the virtual rows 32 nw .. 32 nw + 31; rows
   // >= S (tile padding) are clamped duplicates -- every product treats token rows independently -- and only their
   // stores are predicated
-  int prow[TR];
+  int prow[TR], psw[TR];  // physical row of the lane in each row tile, and its column swizzle
   bool lds_ok[TR];
 #pragma unroll
   for (int rt = 0; rt < TR; ++rt) {
     const int sp = (rt & 1) * 16 + c;
     lds_ok[rt] = sp < S;
     prow[rt] = (rt >> 1) * S + (sp < S ? sp : S - 1);
+    psw[rt] = NF_SWZ(prow[rt]);
   }
   // the row tiles wr * TRC .. of the out-projection
-  int prow_c[TRC];
+  int prow_c[TRC], psw_c[TRC];
   bool ok_c[TRC];
 #pragma unroll
   for (int i = 0; i < TRC; ++i) {
@@ -274,6 +287,7 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
     const int sp = (rt & 1) * 16 + c;
     ok_c[i] = sp < S;
     prow_c[i] = (rt >> 1) * S + (sp < S ? sp : S - 1);
+    psw_c[i] = NF_SWZ(prow_c[i]);
   }
 
   f32x4 yacc[TY][TRC];
@@ -320,7 +334,7 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
         int kc = ks * 16 + 4 * g;
         if (kc > D - 4) kc = D - 4;  // k tail: the weight image is zero there, the read only has to stay inside the row
 #pragma unroll
-        for (int rt = NPW * h; rt < NPW * h + NPW; ++rt) fb[st][rt] = *reinterpret_cast<const f32x4*>(&r1[prow[rt] * LY + kc]);
+        for (int rt = NPW * h; rt < NPW * h + NPW; ++rt) fb[st][rt] = *reinterpret_cast<const f32x4*>(&r1[prow[rt] * LY + (kc ^ psw[rt])]);
       };
       auto mma = [&](auto ST, auto J) {
         constexpr int st = decltype(ST)::value, j = decltype(J)::value;
@@ -342,7 +356,7 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
           const f32x4 bv = *reinterpret_cast<const f32x4*>(img + im.off_bqkv(grp) + (wave * TF + t) * 16 + 4 * g);
 #pragma unroll
           for (int rt = 0; rt < TR; ++rt)
-            if (lds_ok[rt]) *reinterpret_cast<f32x4*>(&r2[prow[rt] * LQ + f0]) = acc[t][rt] + bv;
+            if (lds_ok[rt]) *reinterpret_cast<f32x4*>(&r2[prow[rt] * LQ + (f0 ^ psw[rt])]) = acc[t][rt] + bv;
         }
       }
     }
@@ -354,9 +368,8 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
       const int n_units = NPW * nh;
       for (int u = wave; u < n_units; u += 8) {
         const int nw = u / nh, hh = u - nw * nh;
-        float* Qb = r2 + (nw * S) * LQ + hh * dk;
-        const float* Kb = Qb + NW;
-        const float* Vb = Qb + 2 * NW;
+        const int R0 = nw * S;                                        // first row of this news in the image
+        const int cQ = hh * dk, cK = NW + hh * dk, cV = 2 * NW + hh * dk;  // column bases of the head's Q, K, V
         int64_t news = news0 + nw;
         if (news >= a.n_seq) news = a.n_seq - 1;
         const int64_t msrc = a.ids ? (int64_t)a.ids[news] : news;
@@ -368,11 +381,12 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
         for (int kt = 0; kt < 2; ++kt) {
           int key = 16 * kt + c;
           if (key > S - 1) key = S - 1;
-          const float* kp = Kb + key * LQ;
+          const float* kp = r2 + (R0 + key) * LQ;
+          const int swk = NF_SWZ(R0 + key);
 #pragma unroll
-          for (int fb = 0; fb < nfull; ++fb) kf[kt][fb] = *reinterpret_cast<const f32x4*>(kp + 16 * fb + 4 * g);
+          for (int fb = 0; fb < nfull; ++fb) kf[kt][fb] = *reinterpret_cast<const f32x4*>(kp + ((cK + 16 * fb + 4 * g) ^ swk));
 #pragma unroll
-          for (int e = 0; e < nrem; ++e) kr[kt][e] = kp[16 * nfull + 4 * e + g];
+          for (int e = 0; e < nrem; ++e) kr[kt][e] = kp[(cK + 16 * nfull + 4 * e + g) ^ swk];
         }
         // V^T fragments: vv[kt][dt][r] = V[key 16 kt + 4 g + r][16 dt + c]
         float vv[2][ndt][4];
@@ -385,7 +399,7 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
               int key = 16 * kt + 4 * g + r;
               if (key > S - 1) key = S - 1;  // its probability is exactly 0
               const int dv = 16 * dt + c;
-              vv[kt][dt][r] = (dv < dk) ? Vb[key * LQ + dv] : 0.f;
+              vv[kt][dt][r] = (dv < dk) ? r2[(R0 + key) * LQ + ((cV + dv) ^ NF_SWZ(R0 + key))] : 0.f;
             }
         // both 16-query tiles in one straight run (the two softmax chains interleave); for S <= 16 the second tile
         // is a clamped duplicate whose stores are predicated off
@@ -395,12 +409,13 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
         for (int qt = 0; qt < 2; ++qt) {
           const int query = 16 * qt + c;
           qrow[qt] = query < S ? query : S - 1;
-          const float* qp = Qb + qrow[qt] * LQ;
+          const float* qp = r2 + (R0 + qrow[qt]) * LQ;
+          const int swq = NF_SWZ(R0 + qrow[qt]);
           sc[qt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
           sc[qt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int fb = 0; fb < nfull; ++fb) {
-            const f32x4 qf = *reinterpret_cast<const f32x4*>(qp + 16 * fb + 4 * g);
+            const f32x4 qf = *reinterpret_cast<const f32x4*>(qp + ((cQ + 16 * fb + 4 * g) ^ swq));
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -409,7 +424,7 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
           }
 #pragma unroll
           for (int e = 0; e < nrem; ++e) {
-            const float qr = qp[16 * nfull + 4 * e + g];
+            const float qr = qp[(cQ + 16 * nfull + 4 * e + g) ^ swq];
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) sc[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[kt][e], qr, sc[qt][kt], 0, 0, 0);
           }
@@ -462,7 +477,7 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
             const int query = 16 * qt + c, dv0 = 16 * dt + 4 * g;
             if (query < S && dv0 < dk) {
               if (FOLD) *reinterpret_cast<f32x4*>(osc + (size_t)(nw * S + query) * D + (h0 + hh) * dk + dv0) = o;
-              else *reinterpret_cast<f32x4*>(Qb + query * LQ + dv0) = o;
+              else *reinterpret_cast<f32x4*>(r2 + (R0 + query) * LQ + ((cQ + dv0) ^ NF_SWZ(R0 + query))) = o;
             }
           }
       }
@@ -488,7 +503,7 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
       auto load_b = [&](auto ST, int ks, auto HALF) {
         constexpr int st = decltype(ST)::value, h = decltype(HALF)::value;
         const int k = ks * 16 + 4 * g;  // k < NW + 16 <= LQ; columns past NW meet zeros of the image
-        if (h < TRC) fb[st][h] = *reinterpret_cast<const f32x4*>(&r2[prow_c[h < TRC ? h : 0] * LQ + k]);
+        if (h < TRC) fb[st][h] = *reinterpret_cast<const f32x4*>(&r2[prow_c[h < TRC ? h : 0] * LQ + (k ^ psw_c[h < TRC ? h : 0])]);
       };
       auto mma = [&](auto ST, auto J) {
         constexpr int st = decltype(ST)::value, j = decltype(J)::value;
@@ -510,7 +525,7 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
     const int cpr = D >> 2;
     for (int i = tid; i < nrow * cpr; i += NF_THREADS) {
       const int row = i / cpr, ch = i - row * cpr;
-      *reinterpret_cast<f32x4*>(&r1[row * LY + 4 * ch]) = *reinterpret_cast<const f32x4*>(osc + (size_t)row * D + 4 * ch);
+      *reinterpret_cast<f32x4*>(&r1[row * LY + ((4 * ch) ^ NF_SWZ(row))]) = *reinterpret_cast<const f32x4*>(osc + (size_t)row * D + 4 * ch);
     }
   } else {
 #pragma unroll
@@ -520,7 +535,7 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
         const f32x4 bv = *reinterpret_cast<const f32x4*>(img + im.off_bo() + (wf * TY + t) * 16 + 4 * g);
 #pragma unroll
         for (int i = 0; i < TRC; ++i)
-          if (ok_c[i]) *reinterpret_cast<f32x4*>(&r1[prow_c[i] * LY + d0]) = yacc[t][i] + bv;
+          if (ok_c[i]) *reinterpret_cast<f32x4*>(&r1[prow_c[i] * LY + (d0 ^ psw_c[i])]) = yacc[t][i] + bv;
       }
     }
   }
@@ -547,7 +562,7 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
       int kc = ks * 16 + 4 * g;
       if (kc > D - 4) kc = D - 4;
 #pragma unroll
-      for (int rt = NPW * h; rt < NPW * h + NPW; ++rt) fb[st][rt] = *reinterpret_cast<const f32x4*>(&r1[prow[rt] * LY + kc]);
+      for (int rt = NPW * h; rt < NPW * h + NPW; ++rt) fb[st][rt] = *reinterpret_cast<const f32x4*>(&r1[prow[rt] * LY + (kc ^ psw[rt])]);
     };
     auto mma = [&](auto ST, auto J) {
       constexpr int st = decltype(ST)::value, j = decltype(J)::value;
@@ -616,7 +631,7 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < S; ++s) {
       const float w = aw[NPW * 32 + nw * 32 + s];
-      const f32x4 yv = *reinterpret_cast<const f32x4*>(&r1[(nw * S + s) * LY + 4 * d4]);
+      const f32x4 yv = *reinterpret_cast<const f32x4*>(&r1[(nw * S + s) * LY + ((4 * d4) ^ NF_SWZ(nw * S + s))]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[r] = fmaf(w, yv[r], acc[r]);
     }
