@@ -657,10 +657,18 @@ def padding_free_extra(model, hist, cand, steps, scores_dense):
     nz = live.any(dim=1)
     n_tok = float(nz.sum().item() * live.shape[1] + cand[1].numel())
     out["masked_token_rows_of_live_news"] = 1.0 - float(live[nz].sum().item() + cand[1].ne(0).sum().item()) / n_tok
+    from xnrs_amd import ops
+    out["how"] = ("unpadded / skip_empty+unpadded: row lists and counts built on the device (xnrs_text_encoder_fwd_compact): "
+                  "no host read, hipGraph-capturable, all-masked news dropped by the same lists; "
+                  "skip_empty+unpadded_host_lists: the round-2 path (one nonzero per switch and encoder call)")
     for name, flags in (("skip_empty", dict(skip_empty=True)), ("unpadded", dict(unpadded=True)),
-                        ("skip_empty+unpadded", dict(skip_empty=True, unpadded=True))):
+                        ("skip_empty+unpadded", dict(skip_empty=True, unpadded=True)),
+                        ("skip_empty+unpadded_host_lists", dict(skip_empty=True, unpadded=True))):
         for k, v in flags.items():
             setattr(enc, k, v)
+        on_device = ops.COMPACT_ON_DEVICE
+        if name.endswith("host_lists"):
+            ops.COMPACT_ON_DEVICE = False
         try:
             fn = lambda: step(model, hist, cand)  # noqa: E731
             dt = timed(fn, steps, 2, False)
@@ -669,6 +677,7 @@ def padding_free_extra(model, hist, cand, steps, scores_dense):
             diff = ((r - scores_dense).abs().max() / scores_dense.abs().max()).item()
         finally:
             enc.skip_empty = enc.unpadded = False
+            ops.COMPACT_ON_DEVICE = on_device
         # (in the split GEMM modes a launch of fewer than 512 tiles runs on the fp32 kernel, so a different pass
         # size can move a result by fp32 rounding noise; in the default mode the scores are bitwise equal)
         out[name] = dict(impressions_per_s=B * steps / dt, ms_per_step=dt / steps * 1e3, equals_dense=same,
