@@ -269,7 +269,7 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
   // ---- this lane's token row in each row tile: news nw = rt >> 1 owns the virtual rows 32 nw .. 32 nw + 31; rows
   // >= S (tile padding) are clamped duplicates -- every product treats token rows independently -- and only their
   // stores are predicated
-  int prow[TR], psw[TR];  // physical row of the lane in each row tile, and its column swizzle
+  int prow[TR], psw[TR], pdl[TR];  // physical row of the lane in each row tile, its column swizzle, the same as an offset
   bool lds_ok[TR];
 #pragma unroll
   for (int rt = 0; rt < TR; ++rt) {
@@ -277,9 +277,13 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
     lds_ok[rt] = sp < S;
     prow[rt] = (rt >> 1) * S + (sp < S ? sp : S - 1);
     psw[rt] = NF_SWZ(prow[rt]);
+    // columns of the form 16 j + 4 g (k chunks, accumulator chunks): bit 2 is g & 1, so the flip is a per-lane constant
+    // +-4 that rides in the row offset -- no XOR in the k loops.  (A clamped k-tail read lands on D - 4 +- 4 instead of
+    // (D - 4) ^ 4: both are written columns of the row, and the weight image is zero there.)
+    pdl[rt] = psw[rt] ? ((g & 1) ? -4 : 4) : 0;
   }
   // the row tiles wr * TRC .. of the out-projection
-  int prow_c[TRC], psw_c[TRC];
+  int prow_c[TRC], psw_c[TRC], pdl_c[TRC];
   bool ok_c[TRC];
 #pragma unroll
   for (int i = 0; i < TRC; ++i) {
@@ -288,6 +292,7 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
     ok_c[i] = sp < S;
     prow_c[i] = (rt >> 1) * S + (sp < S ? sp : S - 1);
     psw_c[i] = NF_SWZ(prow_c[i]);
+    pdl_c[i] = psw_c[i] ? ((g & 1) ? -4 : 4) : 0;
   }
 
   f32x4 yacc[TY][TRC];
@@ -334,7 +339,7 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
         int kc = ks * 16 + 4 * g;
         if (kc > D - 4) kc = D - 4;  // k tail: the weight image is zero there, the read only has to stay inside the row
 #pragma unroll
-        for (int rt = NPW * h; rt < NPW * h + NPW; ++rt) fb[st][rt] = *reinterpret_cast<const f32x4*>(&r1[prow[rt] * LY + (kc ^ psw[rt])]);
+        for (int rt = NPW * h; rt < NPW * h + NPW; ++rt) fb[st][rt] = *reinterpret_cast<const f32x4*>(&r1[prow[rt] * LY + pdl[rt] + kc]);
       };
       auto mma = [&](auto ST, auto J) {
         constexpr int st = decltype(ST)::value, j = decltype(J)::value;
@@ -356,7 +361,7 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
           const f32x4 bv = *reinterpret_cast<const f32x4*>(img + im.off_bqkv(grp) + (wave * TF + t) * 16 + 4 * g);
 #pragma unroll
           for (int rt = 0; rt < TR; ++rt)
-            if (lds_ok[rt]) *reinterpret_cast<f32x4*>(&r2[prow[rt] * LQ + (f0 ^ psw[rt])]) = acc[t][rt] + bv;
+            if (lds_ok[rt]) *reinterpret_cast<f32x4*>(&r2[prow[rt] * LQ + pdl[rt] + f0]) = acc[t][rt] + bv;
         }
       }
     }
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
       auto load_b = [&](auto ST, int ks, auto HALF) {
         constexpr int st = decltype(ST)::value, h = decltype(HALF)::value;
         const int k = ks * 16 + 4 * g;  // k < NW + 16 <= LQ; columns past NW meet zeros of the image
-        if (h < TRC) fb[st][h] = *reinterpret_cast<const f32x4*>(&r2[prow_c[h < TRC ? h : 0] * LQ + (k ^ psw_c[h < TRC ? h : 0])]);
+        if (h < TRC) fb[st][h] = *reinterpret_cast<const f32x4*>(&r2[prow_c[h < TRC ? h : 0] * LQ + pdl_c[h < TRC ? h : 0] + k]);
       };
       auto mma = [&](auto ST, auto J) {
         constexpr int st = decltype(ST)::value, j = decltype(J)::value;
@@ -535,7 +540,7 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
         const f32x4 bv = *reinterpret_cast<const f32x4*>(img + im.off_bo() + (wf * TY + t) * 16 + 4 * g);
 #pragma unroll
         for (int i = 0; i < TRC; ++i)
-          if (ok_c[i]) *reinterpret_cast<f32x4*>(&r1[prow_c[i] * LY + (d0 ^ psw_c[i])]) = yacc[t][i] + bv;
+          if (ok_c[i]) *reinterpret_cast<f32x4*>(&r1[prow_c[i] * LY + pdl_c[i] + d0]) = yacc[t][i] + bv;
       }
     }
   }
@@ -562,7 +567,7 @@ __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kerne
       int kc = ks * 16 + 4 * g;
       if (kc > D - 4) kc = D - 4;
 #pragma unroll
-      for (int rt = NPW * h; rt < NPW * h + NPW; ++rt) fb[st][rt] = *reinterpret_cast<const f32x4*>(&r1[prow[rt] * LY + (kc ^ psw[rt])]);
+      for (int rt = NPW * h; rt < NPW * h + NPW; ++rt) fb[st][rt] = *reinterpret_cast<const f32x4*>(&r1[prow[rt] * LY + pdl[rt] + kc]);
     };
     auto mma = [&](auto ST, auto J) {
       constexpr int st = decltype(ST)::value, j = decltype(J)::value;
