@@ -17,4 +17,4 @@ timeout -k 10 200 python tools/bench_dw.py > $O/bench_dw.txt 2>&1; echo "dw rc=$
 timeout -k 10 300 python tools/bench_news_fused.py > $O/bench_nf.txt 2>&1; echo "nf bench rc=$?"
 NF_SWEEP=1 timeout -k 10 300 python tools/bench_news_fused.py > $O/bench_nf_sweep.txt 2>&1; echo "nf sweep rc=$?"
 timeout -k 10 200 python tools/bench_compact.py > $O/bench_compact.txt 2>&1; echo "compact rc=$?"
-tail -4 $O/bench_af.txt $O/bench_dw.txt
+tail -n 4 $O/bench_af.txt; tail -n 4 $O/bench_dw.txt
