@@ -844,7 +844,7 @@ int32_t xnrs_text_encoder_fwd_unpadded(const float* x, const int32_t* ids, int64
 namespace {
 struct CompactPlan {
   int64_t chunk;
-  size_t off_kv, off_q, off_o, off_t, off_roff, off_live, off_kvs, off_kvd, off_cnt, off_p, off_h, off_fw, off_fb, off_po,
+  size_t off_kv, off_q, off_o, off_t, off_roff, off_live, off_kvs, off_kvb, off_cnt, off_p, off_h, off_fw, off_fb, off_po,
       off_as, off_fsl, total;
 };
 CompactPlan make_compact_plan(int64_t n_news, int S, int D, int A, int E, bool att, bool head, int64_t chunk) {
@@ -869,7 +869,7 @@ CompactPlan make_compact_plan(int64_t n_news, int S, int D, int A, int E, bool a
   p.off_roff = take(passes * ((size_t)chunk + 1) * 8);  // the row lists of EVERY pass (one compaction launch per call)
   p.off_live = take(passes * rows * 4);
   p.off_kvs = take(passes * rows * 4);
-  p.off_kvd = take(passes * rows * 4);
+  p.off_kvb = take(passes * (size_t)chunk * 4);
   p.off_cnt = take(passes * 3 * 8);  // {live rows, K|V rows, bad-mask flag} per pass
   p.off_p = head ? take((size_t)n_news * D * 4) : 0;
   p.off_h = head ? take((size_t)n_news * E * 4) : 0;
@@ -914,7 +914,7 @@ int32_t xnrs_text_encoder_fwd_compact(const float* x, const float* m, const int3
   int64_t* roff0 = reinterpret_cast<int64_t*>(w + p.off_roff);
   int32_t* live0 = reinterpret_cast<int32_t*>(w + p.off_live);
   int32_t* kvs0 = reinterpret_cast<int32_t*>(w + p.off_kvs);
-  int32_t* kvd0 = reinterpret_cast<int32_t*>(w + p.off_kvd);
+  int32_t* kvb0 = reinterpret_cast<int32_t*>(w + p.off_kvb);
   int64_t* cnt0 = reinterpret_cast<int64_t*>(w + p.off_cnt);
   float* pb = reinterpret_cast<float*>(w + p.off_p);
   float* hb = reinterpret_cast<float*>(w + p.off_h);
@@ -939,7 +939,7 @@ int32_t xnrs_text_encoder_fwd_compact(const float* x, const float* m, const int3
   }
   if (att && !fold) return XNRS_EUNSUPPORTED;  // (the per-token out-projection order: use the host-compacted entry point)
   const int n_ep = (A + 31) / 32;
-  XNRS_TRY(launch_compact_rows(m, ids, n_news, p.chunk, S, roff0, live0, kvs0, kvd0, cnt0, stream));
+  XNRS_TRY(launch_compact_rows(m, ids, n_news, p.chunk, S, roff0, live0, kvs0, kvb0, cnt0, stream));
   for (int64_t c0 = 0; c0 < n_news; c0 += p.chunk) {
     const int64_t nc = (n_news - c0 < p.chunk) ? (n_news - c0) : p.chunk;
     const int64_t rows = nc * S;  // worst case
@@ -948,18 +948,17 @@ int32_t xnrs_text_encoder_fwd_compact(const float* x, const float* m, const int3
     const int64_t* roff = roff0 + pass * (p.chunk + 1);
     const int32_t* live = live0 + pass * p.chunk * S;
     const int32_t* kvs = kvs0 + pass * p.chunk * S;
-    const int32_t* kvd = kvd0 + pass * p.chunk * S;
+    const int32_t* kvb = kvb0 + pass * p.chunk;
     const float* vals = x;           // what the pooler weights: compact O rows, or x rows through `live`
     const int32_t* val_ids = live;
     if (att) {
       const int dk = D / att->n_heads;
-      {  // K and V of every token of the news that have a live token (rows gathered AND scattered through the device lists)
+      {  // K and V of every token of the news that have a live token: rows gathered through the device list, written as
+         // consecutive S-row blocks (the attention kernel finds a news' block through kv_block: no row scatter)
         GemmArgs g{};
         g.A = x;
         g.gather_ids = kvs;
         g.gather_S = 1;
-        g.c_scatter = 1;
-        g.c_scatter_ids = kvd;
         g.lda = D;
         g.W[0] = att->wk; g.W[1] = att->wv;
         g.bias[0] = att->bk; g.bias[1] = att->bv;
@@ -981,6 +980,7 @@ int32_t xnrs_text_encoder_fwd_compact(const float* x, const float* m, const int3
       ma.q = qc;
       ma.q_off = roff;
       ma.ldq = D;
+      ma.kv_block = kvb;
       ma.k = kv;
       ma.v = kv + D;
       ma.ld = 2 * (int64_t)D;

@@ -244,14 +244,15 @@ hipError_t launch_gather_rows(const float* table, const int32_t* ids, float* out
 // row three times: 109 us per pass, 2.4 ms of a 50 ms step.)
 //   row_off [chunk+1]   compact range of news j: row_off[j] .. row_off[j+1]
 //   live_src [<= chunk*S]  source token row (x row space: ids[news]*S + s with a table, else news*S + s) of compact row i
-//   kv_src / kv_dst [<= chunk*S]  source row / row inside this pass's padded [chunk*S] K|V image of the i-th kept token row
+//   kv_src [<= chunk*S]  source row of the i-th kept token row: the K|V image of a pass holds the non-empty news as
+//                        CONSECUTIVE blocks of S rows; kv_block[j] = block of news j (the attention kernel's MhaCoreArgs::kv_block)
 //   counts[0] = live rows, counts[1] = kept K|V rows      (device scalars the GEMMs read: GemmArgs::m_dev)
 //   counts[2] = 1 if a mask value other than 0 / 1 was seen: the pooling kernel then writes NaN instead of a result that
 //               would silently differ from the reference's exp(e) * m (there is no host read here to raise from)
 __global__ __launch_bounds__(1024) void compact_rows_kernel(const float* __restrict__ mask, const int32_t* __restrict__ ids,
                                                              int64_t n_news, int64_t chunk, int S, int64_t* __restrict__ row_off_all,
                                                              int32_t* __restrict__ live_all, int32_t* __restrict__ kvs_all,
-                                                             int32_t* __restrict__ kvd_all, int64_t* __restrict__ counts_all) {
+                                                             int32_t* __restrict__ kvb_all, int64_t* __restrict__ counts_all) {
   __shared__ int s_cnt[1024];
   __shared__ int s_ex[2][1024];
   __shared__ int s_wsum[2][16];
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(1024) void compact_rows_kernel(const float* __restr
   int64_t* row_off = row_off_all + (int64_t)blockIdx.x * (chunk + 1);
   int32_t* live_src = live_all + (int64_t)blockIdx.x * chunk * S;
   int32_t* kv_src = kvs_all + (int64_t)blockIdx.x * chunk * S;
-  int32_t* kv_dst = kvd_all + (int64_t)blockIdx.x * chunk * S;
+  int32_t* kv_block = kvb_all + (int64_t)blockIdx.x * chunk;
   int64_t* counts = counts_all + 3 * (int64_t)blockIdx.x;
   const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;  // the lanes before this one
   int bad = 0;
@@ -327,11 +328,9 @@ __global__ __launch_bounds__(1024) void compact_rows_kernel(const float* __restr
         const uint64_t b = __ballot(on);
         if (on) live_src[w + __popcll(b & below)] = (int32_t)(src0 + sl);
         w += __popcll(b);
-        if (kept && sl < S) {
-          kv_src[e1 + sl] = (int32_t)(src0 + sl);
-          kv_dst[e1 + sl] = j * S + sl;
-        }
+        if (kept && sl < S) kv_src[e1 + sl] = (int32_t)(src0 + sl);
       }
+      if (lane == 0) kv_block[j] = e1 / S;  // (an empty news: the block the next non-empty one gets -- never read)
     }
     __syncthreads();
   }
@@ -361,12 +360,12 @@ hipError_t launch_poison(float* y, int64_t n, const int64_t* flags, int n_flags,
 }
 
 hipError_t launch_compact_rows(const float* mask, const int32_t* ids, int64_t n_news, int64_t chunk, int S, int64_t* row_off,
-                               int32_t* live_src, int32_t* kv_src, int32_t* kv_dst, int64_t* counts, hipStream_t stream) {
+                               int32_t* live_src, int32_t* kv_src, int32_t* kv_block, int64_t* counts, hipStream_t stream) {
   if (n_news <= 0 || chunk <= 0) return hipSuccess;
   const int64_t passes = (n_news + chunk - 1) / chunk;
   if (passes > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned)passes), dim3(1024), 0, stream, mask, ids, n_news, chunk, S, row_off,
-                     live_src, kv_src, kv_dst, counts);
+                     live_src, kv_src, kv_block, counts);
   return hipGetLastError();
 }
 

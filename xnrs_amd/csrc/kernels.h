@@ -157,6 +157,9 @@ struct MhaCoreArgs {
   // (mask is ignored), K and V keep the padded [n_seq*S] addressing.  LDS-staged kernel only (S, d_k <= 64).
   const int64_t* q_off;
   int64_t ldq;
+  // with q_off (nullable): K and V of sequence n are block kv_block[n] of the [.., S] row image (seq_stride apart) instead
+  // of block n -- the device-compacted encoder projects K|V of the non-empty news into consecutive blocks (no row scatter)
+  const int32_t* kv_block;
   // 1 (optional, with mask; pair kernel only, ignored elsewhere): a sequence whose query rows are ALL masked is not
   // computed -- its output rows are written as zeros and its statistics as those of masked rows {-1e9, S}.  For callers
   // whose consumers give masked rows a zero weight (the training forward over live rows, api.hip): such rows reach
@@ -463,9 +466,9 @@ hipError_t launch_gather_rows(const float* table, const int32_t* ids, float* out
                               hipStream_t stream);
 hipError_t launch_poison(float* y, int64_t n, const int64_t* flags, int n_flags, int flag_stride, hipStream_t stream);
 // live-row / kept-K|V-row lists + CSR offsets of every pass of `chunk` news, built on the device in one launch (batch.hip):
-// pass p writes row_off[p*(chunk+1) ..], the lists at [p*chunk*S ..], counts[3*p ..]
+// pass p writes row_off[p*(chunk+1) ..], the lists at [p*chunk*S ..], kv_block[p*chunk ..], counts[3*p ..]
 hipError_t launch_compact_rows(const float* mask, const int32_t* ids, int64_t n_news, int64_t chunk, int S, int64_t* row_off,
-                               int32_t* live_src, int32_t* kv_src, int32_t* kv_dst, int64_t* counts, hipStream_t stream);
+                               int32_t* live_src, int32_t* kv_src, int32_t* kv_block, int64_t* counts, hipStream_t stream);
 hipError_t launch_assemble_train(const BatchArgs& a, hipStream_t stream);
 hipError_t launch_assemble_eval(const BatchArgs& a, hipStream_t stream);
 hipError_t launch_score_csr(const float* vecs, const int32_t* rows, const int32_t* sess, const float* u, float* r, int64_t n,

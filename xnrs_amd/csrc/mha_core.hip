@@ -336,8 +336,9 @@ __global__ __launch_bounds__(256) void mha_core_lds_kernel(MhaCoreArgs a, int64_
   const int hoff = hd * dk;
   const int ld = (int)a.ld;
   const int64_t hbase = seq * a.seq_stride + hd * a.head_stride;
-  const float* kbase = a.k + hbase;
-  const float* vbase = a.v + hbase;
+  const int64_t kvbase = (a.q_off && a.kv_block) ? (int64_t)a.kv_block[seq] * a.seq_stride + hd * a.head_stride : hbase;
+  const float* kbase = a.k + kvbase;
+  const float* vbase = a.v + kvbase;
 
   // this wave's query fragments and mask value are fetched FIRST so their latency overlaps the K/V staging
   // (they do not depend on it)
@@ -521,8 +522,9 @@ __global__ __launch_bounds__(256, (KTM * NFB <= 9 ? 8 : 5)) void mha_core_pair_k
   const int S = a.S, dk = a.d_k;
   const int ld = (int)a.ld;
   const int64_t hbase = (int64_t)seq * a.seq_stride + (int64_t)hd * a.head_stride;
-  const float* kbase = a.k + hbase;
-  const float* vbase = a.v + hbase;
+  const int64_t kvbase = (a.q_off && a.kv_block) ? (int64_t)a.kv_block[seq] * a.seq_stride + (int64_t)hd * a.head_stride : hbase;
+  const float* kbase = a.k + kvbase;
+  const float* vbase = a.v + kvbase;
   const int rem = TAIL ? S - KTM * 16 : 0;  // 1..4 (launcher)
 
   // ---- this wave's query fragments and mask value first: their latency overlaps the staging
@@ -530,6 +532,7 @@ __global__ __launch_bounds__(256, (KTM * NFB <= 9 ? 8 : 5)) void mha_core_pair_k
   const int64_t q0 = a.q_off ? a.q_off[seq] : (int64_t)seq * S;
   const int nq = a.q_off ? (int)(a.q_off[seq + 1] - q0) : S;
   const int QT = (nq + 15) >> 4;
+  if (nq == 0) return;  // (unpadded queries: a news without a live token -- nothing to stage, nothing to write; uniform)
   const int c = lane & 15, g = lane >> 4;
   const int query = qt * 16 + c;
   const bool qvalid = query < nq;
