@@ -21,6 +21,12 @@ with torch.no_grad():
     for i in range(N):
         bad += int(not torch.equal(bench.step(model, hist, cand), ref))
 print(f"forward: {N} steps, {bad} differ from the first", flush=True)
+with torch.no_grad():  # the device-compacted padding-free encoder: equal to the dense step, every time
+    model.news_encoder.unpadded = True
+    for i in range(N):
+        bad += int(not torch.equal(bench.step(model, hist, cand), ref))
+    model.news_encoder.unpadded = False
+print(f"forward, device-compacted: {N} steps, {bad} differ from the dense first step (cumulative)", flush=True)
 
 w2 = dict(B=64, H=25, C=5, S=50, D=768, h=16, E=256, A=256)
 m2, _ = bench.build_model(w2, dev)
