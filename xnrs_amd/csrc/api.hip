@@ -849,7 +849,11 @@ struct CompactPlan {
 };
 CompactPlan make_compact_plan(int64_t n_news, int S, int D, int A, int E, bool att, bool head, int64_t chunk) {
   CompactPlan p{};
-  if (chunk <= 0) chunk = 65536 / S;
+  // default pass: ~262 k token rows (3.2 GB of worst-case scratch at D = 768 -- sized for 288 GB of HBM).  Four times the
+  // padded path's pass: the row counts are only known on the device, so every pass pays the latency of its five launches
+  // even when most of its rows are dead (tools/bench_compact_chunk.py: 95 % empty news 6.1 -> 3.6 ms per 25 600 news,
+  // 50 %: 20.4 -> 18.5 ms; beyond ~10 k news per pass the one-workgroup-per-pass compaction kernel becomes the cost)
+  if (chunk <= 0) chunk = 262144 / S;
   if (chunk > n_news) chunk = n_news;
   if (chunk < 1) chunk = 1;
   p.chunk = chunk;
