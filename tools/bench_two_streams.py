@@ -33,8 +33,9 @@ def clock(fn, reps=6):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
-def run_split(k):
-    streams = [torch.cuda.Stream() for _ in range(k)]
+def run_split(k, prio=False):
+    # prio: the streams alternate between high and normal priority (a high-priority queue's workgroups take freed slots first)
+    streams = [torch.cuda.Stream(priority=(-1 if (prio and i % 2 == 0) else 0)) for i in range(k)]
     bounds = [n * i // k for i in range(k + 1)]
     outs = [None] * k
 
@@ -53,8 +54,9 @@ with torch.no_grad():
     ref = ops.text_encoder(x, m, enc)
     t1 = clock(lambda: ops.text_encoder(x, m, enc))
     print(f"one stream: {t1:.3f} ms", flush=True)
-    for k in (2, 3, 4):
-        fn, outs = run_split(k)
-        tk = clock(fn)
-        y = torch.cat([o[0] for o in outs])
-        print(f"{k} streams: {tk:.3f} ms  ({t1 / tk:.3f}x)  equal {torch.equal(y, ref[0])}", flush=True)
+    for prio in (False, True):
+        for k in (2, 3, 4):
+            fn, outs = run_split(k, prio)
+            tk = clock(fn)
+            y = torch.cat([o[0] for o in outs])
+            print(f"{k} streams{' (alternating priority)' if prio else ''}: {tk:.3f} ms  ({t1 / tk:.3f}x)  equal {torch.equal(y, ref[0])}", flush=True)
