@@ -111,3 +111,11 @@ def test_header_is_plain_c_and_cxx(tmp_path):
                 ["g++", "-std=c++17", "-Wall", "-Werror", "-I", inc, "-x", "c++", "-c", str(src), "-o", str(tmp_path / "cxx.o")]):
         r = subprocess.run(cmd, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_graft_entry_build_agrees_with_the_header():
+    """__graft_entry__.build() (the driver's "does it build" check) compiles -- a no-op when the library is current --
+    imports the package and checks the library's ABI version against include/xnrs_hip.h; it must not carry a number
+    of its own that a header bump leaves behind."""
+    import __graft_entry__ as g
+    g.build()
