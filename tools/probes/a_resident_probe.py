@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 from xnrs_amd import hip  # noqa: E402
 
 dev = torch.device("cuda", 0)
-K, M = 768, 65536
+K, M = 768, int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 g = torch.Generator(device=dev)
 g.manual_seed(1)
 x = torch.randn(M, K, device=dev, generator=g)
