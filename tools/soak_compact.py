@@ -52,7 +52,8 @@ for it in range(n_cfg):
             print("skip", tag, flush=True)
             continue
         with torch.no_grad():
-            y0, hm0 = ops.text_encoder(x, m.unsqueeze(-1), enc, ids=ids)
+            with hip.knobs(XNRS_NEWS_FUSED="0"):  # the padded GEMM pipeline (the fused short-title kernel differs by ~1e-7)
+                y0, hm0 = ops.text_encoder(x, m.unsqueeze(-1), enc, ids=ids)
             hip.release_workspaces()
             junk = [torch.full((8 << 20,), float("nan"), device=dev) for _ in range(6)]
             del junk

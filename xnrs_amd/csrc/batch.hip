@@ -342,6 +342,91 @@ __global__ __launch_bounds__(1024) void compact_rows_kernel(const float* __restr
   }
 }
 
+// The same lists for S <= 64 (every shape with an attention tower), throughput-shaped: the mask of a round of 1 024 news is
+// read ONCE, flattened over the workgroup (element i -> news i / S, token i % S: coalesced, ~50 independent loads per
+// thread instead of a wave walking 64 news one dependent load at a time), each live token sets its bit in the news' 64-bit
+// word in LDS; counts are popcounts, and the lists are written by the same flattened sweep (a live token's place = the
+// news' offset + the popcount of the bits below it).  378 -> ~100 us per call of 25 600 news x 50 (it sits on the critical
+// path of the device-compacted encoder: 2.5 % of the padding-free benchmark step).
+__global__ __launch_bounds__(1024) void compact_rows64_kernel(const float* __restrict__ mask, const int32_t* __restrict__ ids,
+                                                               int64_t n_news, int64_t chunk, int S, int64_t* __restrict__ row_off_all,
+                                                               int32_t* __restrict__ live_all, int32_t* __restrict__ kvs_all,
+                                                               int32_t* __restrict__ kvb_all, int64_t* __restrict__ counts_all) {
+  __shared__ unsigned long long s_bits[1024];
+  __shared__ int64_t s_row[1024];
+  __shared__ int s_ex[2][1024];
+  __shared__ int s_wsum[2][16];
+  __shared__ int s_carry[2];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t news0 = (int64_t)blockIdx.x * chunk;
+  const int cn = (int)(n_news - news0 < chunk ? n_news - news0 : chunk);
+  int64_t* row_off = row_off_all + (int64_t)blockIdx.x * (chunk + 1);
+  int32_t* live_src = live_all + (int64_t)blockIdx.x * chunk * S;
+  int32_t* kv_src = kvs_all + (int64_t)blockIdx.x * chunk * S;
+  int32_t* kv_block = kvb_all + (int64_t)blockIdx.x * chunk;
+  int64_t* counts = counts_all + 3 * (int64_t)blockIdx.x;
+  int bad = 0;
+  if (tid < 2) s_carry[tid] = 0;
+  if (tid == 0) row_off[0] = 0;
+  for (int base = 0; base < cn; base += 1024) {
+    const int nn = cn - base < 1024 ? cn - base : 1024;
+    s_bits[tid] = 0ull;
+    s_row[tid] = tid < nn ? (ids ? (int64_t)ids[news0 + base + tid] : news0 + base + tid) : 0;
+    __syncthreads();
+    const int n_el = nn * S;
+    for (int i = tid; i < n_el; i += 1024) {
+      const int jj = i / S, sl = i - jj * S;
+      const float mv = mask[s_row[jj] * S + sl];
+      bad |= (mv != 0.f && mv != 1.f) ? 1 : 0;
+      if (mv != 0.f) atomicOr(&s_bits[jj], 1ull << sl);
+    }
+    __syncthreads();
+    const unsigned long long bits = s_bits[tid];
+    const int cnt = __popcll(bits);
+    const int v[2] = {cnt, cnt > 0 ? S : 0};
+    int incl[2];
+    for (int which = 0; which < 2; ++which) {
+      int x = v[which];
+      for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(x, off);
+        if (lane >= off) x += up;
+      }
+      incl[which] = x;
+      if (lane == 63) s_wsum[which][wave] = x;
+    }
+    __syncthreads();
+    for (int which = 0; which < 2; ++which) {
+      int before = s_carry[which];
+      for (int w = 0; w < wave; ++w) before += s_wsum[which][w];
+      s_ex[which][tid] = before + incl[which] - v[which];
+    }
+    if (tid < nn) {
+      row_off[base + tid + 1] = s_ex[0][tid] + cnt;
+      kv_block[base + tid] = s_ex[1][tid] / S;  // (an empty news: the block the next non-empty one gets -- never read)
+    }
+    __syncthreads();
+    if (tid == 1023) {
+      s_carry[0] = s_ex[0][1023] + v[0];
+      s_carry[1] = s_ex[1][1023] + v[1];
+    }
+    for (int i = tid; i < n_el; i += 1024) {
+      const int jj = i / S, sl = i - jj * S;
+      const unsigned long long b = s_bits[jj];
+      if (b == 0ull) continue;
+      const int32_t src = (int32_t)(s_row[jj] * S + sl);
+      kv_src[s_ex[1][jj] + sl] = src;
+      if ((b >> sl) & 1ull) live_src[s_ex[0][jj] + __popcll(b & ((1ull << sl) - 1ull))] = src;
+    }
+    __syncthreads();
+  }
+  bad = __syncthreads_or(bad);
+  if (tid == 0) {
+    counts[0] = s_carry[0];
+    counts[1] = s_carry[1];
+    counts[2] = bad ? 1 : 0;
+  }
+}
+
 // NaN over a result whose precondition turned out violated on the device (the flags of every pass, OR-ed)
 __global__ __launch_bounds__(256) void poison_kernel(float* y, int64_t n, const int64_t* flags, int n_flags, int flag_stride) {
   bool bad = false;
@@ -364,8 +449,12 @@ hipError_t launch_compact_rows(const float* mask, const int32_t* ids, int64_t n_
   if (n_news <= 0 || chunk <= 0) return hipSuccess;
   const int64_t passes = (n_news + chunk - 1) / chunk;
   if (passes > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned)passes), dim3(1024), 0, stream, mask, ids, n_news, chunk, S, row_off,
-                     live_src, kv_src, kv_block, counts);
+  if (S <= 64)
+    hipLaunchKernelGGL(compact_rows64_kernel, dim3((unsigned)passes), dim3(1024), 0, stream, mask, ids, n_news, chunk, S, row_off,
+                       live_src, kv_src, kv_block, counts);
+  else
+    hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned)passes), dim3(1024), 0, stream, mask, ids, n_news, chunk, S, row_off,
+                       live_src, kv_src, kv_block, counts);
   return hipGetLastError();
 }
 
