@@ -356,6 +356,14 @@ def other_models_extra(device, steps=5, warmup=2):
                                    "unit": "TFLOP/s", "frac": (f_fl / (f_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS) if f_ms > 0 else 0.0,
                                    "launches_timed": f_n, "avg_launch_ms": f_ms / max(f_n, 1), "traffic": None},
                          parity_max_rel_err_vs_cpu=err)
+        if name == "standard":  # the same forward without the masked token rows (device-compacted encoder)
+            model.news_encoder.unpadded = True
+            try:
+                dt_u = timed(fn, steps, warmup, False) / steps
+                out[name]["unpadded"] = dict(impressions_per_s=B / dt_u, ms=dt_u * 1e3, equals_dense=bool(torch.equal(fn(), r)),
+                                             masked_token_rows=1.0 - float(hist["title_emb"][1].mean().item()))
+            finally:
+                model.news_encoder.unpadded = False
     return out
 
 
