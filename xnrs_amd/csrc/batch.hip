@@ -346,8 +346,9 @@ __global__ __launch_bounds__(1024) void compact_rows_kernel(const float* __restr
 // read ONCE, flattened over the workgroup (element i -> news i / S, token i % S: coalesced, ~50 independent loads per
 // thread instead of a wave walking 64 news one dependent load at a time), each live token sets its bit in the news' 64-bit
 // word in LDS; counts are popcounts, and the lists are written by the same flattened sweep (a live token's place = the
-// news' offset + the popcount of the bits below it).  378 -> ~100 us per call of 25 600 news x 50 (it sits on the critical
-// path of the device-compacted encoder: 2.5 % of the padding-free benchmark step).
+// news' offset + the popcount of the bits below it).  378 -> 249 us per call of 25 600 news x 50 in five passes (it sits on
+// the critical path of the device-compacted encoder; one workgroup per pass is what bounds it now: the passes' rounds of
+// 1 024 news run one after the other).
 __global__ __launch_bounds__(1024) void compact_rows64_kernel(const float* __restrict__ mask, const int32_t* __restrict__ ids,
                                                                int64_t n_news, int64_t chunk, int S, int64_t* __restrict__ row_off_all,
                                                                int32_t* __restrict__ live_all, int32_t* __restrict__ kvs_all,
