@@ -375,11 +375,22 @@ __global__ __launch_bounds__(1024) void compact_rows64_kernel(const float* __res
     s_row[tid] = tid < nn ? (ids ? (int64_t)ids[news0 + base + tid] : news0 + base + tid) : 0;
     __syncthreads();
     const int n_el = nn * S;
-    for (int i = tid; i < n_el; i += 1024) {
-      const int jj = i / S, sl = i - jj * S;
-      const float mv = mask[s_row[jj] * S + sl];
-      bad |= (mv != 0.f && mv != 1.f) ? 1 : 0;
-      if (mv != 0.f) atomicOr(&s_bits[jj], 1ull << sl);
+    // four elements per trip, their loads issued together (the sweep is latency-bound: one load, one LDS atomic per element)
+    for (int i0 = tid; i0 < n_el; i0 += 4096) {
+      float mv[4];
+      int jj[4], sl[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 1024 * u;
+        jj[u] = (i < n_el ? i : 0) / S;
+        sl[u] = (i < n_el ? i : 0) - jj[u] * S;
+        mv[u] = i < n_el ? mask[s_row[jj[u]] * S + sl[u]] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        bad |= (mv[u] != 0.f && mv[u] != 1.f) ? 1 : 0;
+        if (mv[u] != 0.f) atomicOr(&s_bits[jj[u]], 1ull << sl[u]);
+      }
     }
     __syncthreads();
     const unsigned long long bits = s_bits[tid];
@@ -410,6 +421,7 @@ __global__ __launch_bounds__(1024) void compact_rows64_kernel(const float* __res
       s_carry[0] = s_ex[0][1023] + v[0];
       s_carry[1] = s_ex[1][1023] + v[1];
     }
+#pragma unroll 4
     for (int i = tid; i < n_el; i += 1024) {
       const int jj = i / S, sl = i - jj * S;
       const unsigned long long b = s_bits[jj];
