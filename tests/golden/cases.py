@@ -84,6 +84,10 @@ GRAD = dict(model="NRMS", B=4, H=3, C=3, S=8, D=32, h=4, E=16, bias=False, seed=
 # flat indices grad_sample_idx(numel) -- a multiplicative hash walk, the same on every machine.
 GRAD_SHIPPED = dict(model="NRMS", B=3, H=3, C=2, S=50, D=768, h=16, E=256, bias=False, seed=410, min_len=5,
                     temperature=0.08, lambda_cl=0.1, themes=["theme1", "theme1", "theme0"])
+# the same step for the attention-free bi-encoder of BASELINE configs[3] (config/mind_small_CL.yml: StandardRec, additive
+# towers + heads, biases on) at the shipped token shape: pins the live-row grad step of attention-free towers (round 3)
+GRAD_SHIPPED_STD = dict(model="standard", B=3, H=4, C=2, S=50, D=768, h=16, E=256, bias=True, seed=430, min_len=5,
+                        temperature=0.08, lambda_cl=0.1, themes=["theme2", "theme0", "theme2"])
 GRAD_SAMPLE_MIN, GRAD_SAMPLE_N = 8192, 4096
 
 

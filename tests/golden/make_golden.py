@@ -186,12 +186,12 @@ def grad_cases():
     return out
 
 
-def grad_shipped_cases():
+def grad_shipped_cases(c=None, pre="gs"):
     """The train step of grad_cases() at the shipped NRMS shape (cases.GRAD_SHIPPED): loss terms whole, every gradient
     whole or as its fixed sample (cases.grad_sample).  Two of the three impressions share a theme, so the InfoNCE term is live
     (with two impressions its only negative IS the positive: loss 0)."""
     out = {}
-    c = cases.GRAD_SHIPPED
+    c = c or cases.GRAD_SHIPPED
     model = load(make_model(Cfg(cases.model_cfg(c))), c["seed"] + 1)
     batch = cases.model_batch(c)
     hx, hm = batch["user_features"]["history"]["title_emb"]
@@ -204,12 +204,12 @@ def grad_shipped_cases():
     loss_cl = reference_infonce(model.get_user_embeddings(batch), labels, c["temperature"])
     loss = loss_rec + c["lambda_cl"] * loss_cl
     loss.backward()
-    out["gs/loss"], out["gs/loss_rec"], out["gs/loss_cl"] = npy(loss), npy(loss_rec), npy(loss_cl)
-    out["gs/d_hist_x"], out["gs/d_cand_x"] = cases.grad_sample(hx.grad), cases.grad_sample(cx.grad)
+    out[f"{pre}/loss"], out[f"{pre}/loss_rec"], out[f"{pre}/loss_cl"] = npy(loss), npy(loss_rec), npy(loss_cl)
+    out[f"{pre}/d_hist_x"], out[f"{pre}/d_cand_x"] = cases.grad_sample(hx.grad), cases.grad_sample(cx.grad)
     for k, p in model.named_parameters():
         if p.grad is not None:
-            out[f"gs/dW/{k}"] = cases.grad_sample(p.grad)
-            out[f"gs/max/{k}"] = npy(p.grad.abs().max())  # scale of the whole tensor (a sample may miss its largest entries)
+            out[f"{pre}/dW/{k}"] = cases.grad_sample(p.grad)
+            out[f"{pre}/max/{k}"] = npy(p.grad.abs().max())  # scale of the whole tensor (a sample may miss its largest entries)
     return out
 
 
@@ -327,6 +327,7 @@ def main():
         "data": data_cases(),
         "naml_ids": naml_data_cases(),
         "grads_shipped": grad_shipped_cases(),
+        "grads_shipped_standard": grad_shipped_cases(cases.GRAD_SHIPPED_STD, "gss"),
     }
     for g, d in groups.items():
         np.savez_compressed(os.path.join(HERE, f"{g}.npz"), **d)

@@ -109,6 +109,41 @@ def test_train_step_matches_reference_golden_shipped_shape(live, monkeypatch):
     assert n >= 28
 
 
+@pytest.mark.parametrize("live", [True, False])
+def test_standardrec_train_step_matches_reference_golden_shipped_shape(live, monkeypatch):
+    """BASELINE configs[3]'s model (StandardRec: attention-free additive towers + heads, biases on) through the same train
+    step at the shipped token shape (cases.GRAD_SHIPPED_STD): loss, input gradients and every parameter gradient of the
+    REAL reference -- with `live`, fc1 forward / dW1 / the input gradient's fc1 term run over the unmasked token rows."""
+    from xnrs_amd import autograd
+    g = H.golden("grads_shipped_standard")
+    c = cases.GRAD_SHIPPED_STD
+    monkeypatch.setattr(autograd, "LIVE_ROWS", live)
+    monkeypatch.setattr(autograd, "LIVE_ROWS_MIN", 1)
+    before = autograd.STATS["live_row_forwards"]
+    model, sd = load(make_model(Cfg(cases.model_cfg(c))), c["seed"] + 1)
+    batch = cases.model_batch(c)
+    hx, hm = batch["user_features"]["history"]["title_emb"]
+    cx, cm = batch["candidate_features"]["title_emb"]
+    hx = hx.to(DEV).requires_grad_(True)
+    cx = cx.to(DEV).requires_grad_(True)
+    batch["user_features"]["history"]["title_emb"] = (hx, hm)
+    batch["candidate_features"]["title_emb"] = (cx, cm)
+    labels = cases.theme_labels(c["themes"]).to(DEV)
+    preds = torch.relu(model(batch))
+    loss_rec = torch.nn.functional.mse_loss(preds, batch["targets"].to(DEV))
+    loss_cl = contrastive_loss(model.get_user_embeddings(batch), labels, c["temperature"])
+    loss = loss_rec + c["lambda_cl"] * loss_cl
+    loss.backward()
+    assert (autograd.STATS["live_row_forwards"] > before) == live
+    H.assert_close(loss, g["gss/loss"], 1e-5)
+    H.assert_close(loss_cl, g["gss/loss_cl"], 1e-5)
+    H.assert_close(cases.grad_sample(hx.grad), g["gss/d_hist_x"], GTOL, "d_hist_x")
+    H.assert_close(cases.grad_sample(cx.grad), g["gss/d_cand_x"], GTOL, "d_cand_x")
+    n = H.assert_sampled_grads_close({k: p.grad for k, p in model.named_parameters() if p.grad is not None}, g, GTOL,
+                                     "gss/dW/", "gss/max/")
+    assert n >= 16
+
+
 @pytest.mark.parametrize("S,D,h", [(8, 32, 4), (30, 300, 15), (50, 64, 4), (9, 18, 3)])
 def test_mha_grads(S, D, h):
     att, sd = load(layers.MultiHeadAttention(h, D), 41)

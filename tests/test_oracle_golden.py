@@ -142,6 +142,32 @@ def test_train_step_at_the_shipped_shape():
     assert n >= 28
 
 
+def test_standardrec_train_step_at_the_shipped_shape():
+    """The same for the attention-free bi-encoder of BASELINE configs[3] (StandardRec, biases on; cases.GRAD_SHIPPED_STD):
+    the oracle against the real reference's loss and (sampled) gradients -- the checker of
+    tests/test_hip_grads.py::test_standardrec_train_step_matches_reference_golden_shipped_shape."""
+    g = H.golden("grads_shipped_standard")
+    c = cases.GRAD_SHIPPED_STD
+    sd = H.state_for(H.model_shapes(c), c["seed"] + 1)
+    sd = {k: v.clone().requires_grad_(not k.endswith("dummy_param")) for k, v in sd.items()}
+    batch = cases.model_batch(c)
+    hx, hm = batch["user_features"]["history"]["title_emb"]
+    cx, cm = batch["candidate_features"]["title_emb"]
+    hx.requires_grad_(True)
+    cx.requires_grad_(True)
+    labels = cases.theme_labels(c["themes"])
+    loss, lrec, lcl = O.train_step_loss(batch, sd, None, labels, c["temperature"], c["lambda_cl"])
+    loss.backward()
+    assert float(g["gss/loss_cl"]) > 0.0
+    H.assert_close(loss, g["gss/loss"], 1e-5)
+    H.assert_close(lrec, g["gss/loss_rec"], 1e-5)
+    H.assert_close(lcl, g["gss/loss_cl"], 1e-5)
+    H.assert_close(cases.grad_sample(hx.grad), g["gss/d_hist_x"], 5e-5)
+    H.assert_close(cases.grad_sample(cx.grad), g["gss/d_cand_x"], 5e-5)
+    n = H.assert_sampled_grads_close({k: v.grad for k, v in sd.items() if v.grad is not None}, g, 5e-5, "gss/dW/", "gss/max/")
+    assert n >= 16
+
+
 def test_quirks_pinned():
     """The parity-critical quirks of SURVEY.md finding 4, checked on the oracle."""
     torch.manual_seed(0)
