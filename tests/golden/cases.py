@@ -88,6 +88,9 @@ GRAD_SHIPPED = dict(model="NRMS", B=3, H=3, C=2, S=50, D=768, h=16, E=256, bias=
 # towers + heads, biases on) at the shipped token shape: pins the live-row grad step of attention-free towers (round 3)
 GRAD_SHIPPED_STD = dict(model="standard", B=3, H=4, C=2, S=50, D=768, h=16, E=256, bias=True, seed=430, min_len=5,
                         temperature=0.08, lambda_cl=0.1, themes=["theme2", "theme0", "theme2"])
+# ... and for BASELINE configs[4]'s model (NAML: title + abstract views, category / subcategory embeddings, feature pooler)
+GRAD_SHIPPED_NAML = dict(model="NAML", B=3, H=3, C=2, S=50, D=768, h=16, E=256, bias=False, seed=450, min_len=5,
+                         temperature=0.08, lambda_cl=0.1, themes=["theme1", "theme3", "theme1"])
 GRAD_SAMPLE_MIN, GRAD_SAMPLE_N = 8192, 4096
 
 

@@ -328,6 +328,7 @@ def main():
         "naml_ids": naml_data_cases(),
         "grads_shipped": grad_shipped_cases(),
         "grads_shipped_standard": grad_shipped_cases(cases.GRAD_SHIPPED_STD, "gss"),
+        "grads_shipped_naml": grad_shipped_cases(cases.GRAD_SHIPPED_NAML, "gsn"),
     }
     for g, d in groups.items():
         np.savez_compressed(os.path.join(HERE, f"{g}.npz"), **d)

@@ -144,6 +144,40 @@ def test_standardrec_train_step_matches_reference_golden_shipped_shape(live, mon
     assert n >= 16
 
 
+@pytest.mark.parametrize("live", [True, False])
+def test_naml_train_step_matches_reference_golden_shipped_shape(live, monkeypatch):
+    """BASELINE configs[4]'s model (NAML) through the train step at the shipped token shape (cases.GRAD_SHIPPED_NAML): loss,
+    title-token input gradients and all 30 parameter gradients of the REAL reference, incl. the category / subcategory
+    embedding tables (deterministic scatter) and the feature pooler."""
+    from xnrs_amd import autograd
+    g = H.golden("grads_shipped_naml")
+    c = cases.GRAD_SHIPPED_NAML
+    monkeypatch.setattr(autograd, "LIVE_ROWS", live)
+    monkeypatch.setattr(autograd, "LIVE_ROWS_MIN", 1)
+    model, sd = load(make_model(Cfg(cases.model_cfg(c))), c["seed"] + 1)
+    batch = synth.batch_to(cases.model_batch(c), DEV)
+    hx, hm = batch["user_features"]["history"]["title_emb"]
+    cx, cm = batch["candidate_features"]["title_emb"]
+    hx = hx.requires_grad_(True)
+    cx = cx.requires_grad_(True)
+    batch["user_features"]["history"]["title_emb"] = (hx, hm)
+    batch["candidate_features"]["title_emb"] = (cx, cm)
+    labels = cases.theme_labels(c["themes"]).to(DEV)
+    preds = torch.relu(model(batch))
+    loss_rec = torch.nn.functional.mse_loss(preds, batch["targets"].to(DEV))
+    ue = model.get_user_embeddings(batch)  # (B, 1, E) un-squeezed (naml.py:146-147); the trainer flattens (training.py:443-444)
+    loss_cl = contrastive_loss(ue.reshape(ue.shape[0], -1), labels, c["temperature"])
+    loss = loss_rec + c["lambda_cl"] * loss_cl
+    loss.backward()
+    H.assert_close(loss, g["gsn/loss"], 1e-5)
+    H.assert_close(loss_cl, g["gsn/loss_cl"], 1e-5)
+    H.assert_close(cases.grad_sample(hx.grad), g["gsn/d_hist_x"], GTOL, "d_hist_x")
+    H.assert_close(cases.grad_sample(cx.grad), g["gsn/d_cand_x"], GTOL, "d_cand_x")
+    n = H.assert_sampled_grads_close({k: p.grad for k, p in model.named_parameters() if p.grad is not None}, g, GTOL,
+                                     "gsn/dW/", "gsn/max/")
+    assert n >= 30
+
+
 @pytest.mark.parametrize("S,D,h", [(8, 32, 4), (30, 300, 15), (50, 64, 4), (9, 18, 3)])
 def test_mha_grads(S, D, h):
     att, sd = load(layers.MultiHeadAttention(h, D), 41)

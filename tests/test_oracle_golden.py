@@ -168,6 +168,38 @@ def test_standardrec_train_step_at_the_shipped_shape():
     assert n >= 16
 
 
+def test_naml_train_step_at_the_shipped_shape():
+    """... and for BASELINE configs[4]'s model (NAML: two additive text views, category / subcategory embeddings through a
+    Linear, feature pooler; cases.GRAD_SHIPPED_NAML): the oracle against the real reference's loss and (sampled) gradients
+    incl. the embedding tables -- the checker of tests/test_hip_grads.py::test_naml_train_step_matches_reference_golden_shipped_shape."""
+    g = H.golden("grads_shipped_naml")
+    c = cases.GRAD_SHIPPED_NAML
+    sd = H.state_for(H.model_shapes(c), c["seed"] + 1)
+    sd = {k: v.clone().requires_grad_(not k.endswith("dummy_param")) for k, v in sd.items()}
+    batch = cases.model_batch(c)
+    hx, hm = batch["user_features"]["history"]["title_emb"]
+    cx, cm = batch["candidate_features"]["title_emb"]
+    hx.requires_grad_(True)
+    cx.requires_grad_(True)
+    labels = cases.theme_labels(c["themes"])
+    lrec = O.mse_relu_loss(O.naml_forward(batch, sd), batch["targets"])
+    ue = O.naml_user_embeddings(batch, sd)
+    lcl = O.contrastive_loss(ue.reshape(ue.shape[0], -1), labels, c["temperature"])
+    loss = lrec + c["lambda_cl"] * lcl
+    loss.backward()
+    assert float(g["gsn/loss_cl"]) > 0.0
+    H.assert_close(loss, g["gsn/loss"], 1e-5)
+    H.assert_close(lrec, g["gsn/loss_rec"], 1e-5)
+    H.assert_close(lcl, g["gsn/loss_cl"], 1e-5)
+    H.assert_close(cases.grad_sample(hx.grad), g["gsn/d_hist_x"], 5e-5)
+    H.assert_close(cases.grad_sample(cx.grad), g["gsn/d_cand_x"], 5e-5)
+    # (2e-4, the GPU tests' bar, instead of 5e-5: the fc2 BIAS gradients are sums that cancel analytically -- sum_i de_i =
+    # (1 - sum a) c ~ 1e-8 c -- so what two fp32 implementations return for them is rounding noise of the terms; the
+    # feature pooler's lands at 1e-4 of the floor scale between the oracle and the reference, both on the CPU)
+    n = H.assert_sampled_grads_close({k: v.grad for k, v in sd.items() if v.grad is not None}, g, 2e-4, "gsn/dW/", "gsn/max/")
+    assert n >= 30
+
+
 def test_quirks_pinned():
     """The parity-critical quirks of SURVEY.md finding 4, checked on the oracle."""
     torch.manual_seed(0)
