@@ -377,8 +377,9 @@ def test_unpadded_encoder_matches_padded(tower):
         from xnrs_amd.hip import XnrsHipError
         with pytest.raises(XnrsHipError):
             ops.text_encoder_forward_unpadded(x, m * 0.5, enc.att, enc.pooler, enc.head)
-        yb, hmb = ops.text_encoder_forward_compact(x, m * 0.5, enc.att, enc.pooler, enc.head)
-        assert torch.isnan(yb).all() and torch.isnan(hmb).all()
+        if ops.compact_supported(S, D, enc.att, enc.pooler):  # (not under XNRS_FOLD_OUT=0 / the split GEMM modes)
+            yb, hmb = ops.text_encoder_forward_compact(x, m * 0.5, enc.att, enc.pooler, enc.head)
+            assert torch.isnan(yb).all() and torch.isnan(hmb).all()
 
 
 def test_naml_with_padding_free_encoders_matches_golden():
@@ -514,6 +515,8 @@ def test_device_compacted_encoder_and_graph_capture(tower):
     att = layers.MultiHeadAttention(h, D) if tower == "nrms" else None
     enc, sd = load(news_encoding.TextEncoder(pooler=layers.AdditiveAttention(D, 256), p_dropout=0.0, out_features=E,
                                              in_features=D, att=att), 231)
+    if not (ops.COMPACT_ON_DEVICE and ops.compact_supported(S, D, att, enc.pooler)):
+        pytest.skip("the device-compacted entry point is switched off by a development knob in this environment")
     rng = synth.rng_for(232)
     n = 700
     x = torch.from_numpy(rng.standard_normal((n, S, D)).astype("float32")).to(DEV)
