@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define XNRS_ABI_VERSION 4
+#define XNRS_ABI_VERSION 5
 
 #define XNRS_OK 0
 #define XNRS_EINVAL (-1)     /* bad shape / NULL pointer */
@@ -259,7 +259,18 @@ typedef struct {
   int64_t n_live;
   const int32_t *kv_rows, *kv_src_rows;
   int64_t n_kv;
+  /* ABI 5, optional: the Q|K|V image ([n_seq*L, 3D] fp32) of ANOTHER training forward over the same input, ids, mask,
+   * row lists and projection weights -- the address of its saved blob + xnrs_seq_encoder_saved_qkv_offset().  The
+   * reference's train step encodes the history twice (training.py:406,409) and, with input dropout 0 (every shipped
+   * config), the two encodes differ only in their attention-dropout draws: the second forward then skips its Q/K/V
+   * projection and reads the first one's image, and so does its backward (which still computes its own dQ|dK|dV and weight
+   * gradients).  Identical results, bit for bit.  The caller keeps the other blob alive until this forward's backward
+   * has run.  NULL: project as usual. */
+  const float *qkv_shared;
 } xnrs_row_lists;
+/* byte offset of the Q|K|V image inside the saved blob of a training forward with these shapes (0 without attention) */
+size_t xnrs_seq_encoder_saved_qkv_offset(int64_t n_seq, int32_t L, int32_t D, int32_t A, int32_t E, int32_t n_heads,
+                                         int32_t pool_kind, int32_t has_head);
 int32_t xnrs_seq_encoder_fwd_train_rows(const float *x, const float *m, const int32_t *ids, int64_t n_seq, int32_t L,
                                         int32_t D, const xnrs_mha_params *att, int32_t pool_kind,
                                         const xnrs_additive_params *pool, const xnrs_head_params *head, float *y,

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_error_strings():
     l = hip.lib()
-    assert l.xnrs_abi_version() == 4
+    assert l.xnrs_abi_version() == 5
     assert b"divisible" in l.xnrs_error_string(-2)
     assert l.xnrs_error_string(0) == b"ok"
 

@@ -643,3 +643,55 @@ def test_folded_out_projection_gradients(live, bias):
     (yo[0] * w.cpu()).sum().backward()
     H.assert_close(dx1, xo.grad, GTOL, "dx vs oracle")
     assert check_param_grads(enc, osd) >= (12 if bias else 7)
+
+
+def test_second_history_encode_reuses_the_first_projection():
+    """The reference's train step encodes the history twice (training.py:406 model(batch), :409 get_user_embeddings(batch)).
+    With input dropout 0 the two Q|K|V images are the same numbers: the second training forward reads the first one's image
+    (autograd._QKV_IMAGES, xnrs_row_lists::qkv_shared) -- loss and every gradient BITWISE equal to the step that projects
+    twice; and no reuse once the input was modified in place or goes through an input dropout."""
+    from xnrs_amd import autograd as AG
+    c = dict(model="NRMS", B=6, H=5, C=3, S=20, D=64, h=4, E=32, bias=False, seed=777, min_len=2)
+    model, sd = load(make_model(Cfg(cases.model_cfg(c))), c["seed"] + 1)
+    model.train()  # attention dropout 0.1 on: the two encodes draw independently, the projection is shared all the same
+    for mod in model.modules():
+        if isinstance(mod, layers.MultiHeadAttention):
+            mod.dropout.p = 0.0  # (deterministic comparison: same probabilities in both runs)
+    batch = synth.batch_to(cases.model_batch(c), DEV)
+    labels = torch.tensor([0, 1, 0, 2, 1, 0], device=DEV)
+
+    def step(share):
+        old, AG.SHARE_QKV = AG.SHARE_QKV, share
+        try:
+            model.zero_grad(set_to_none=True)
+            before = AG.STATS["shared_qkv_forwards"]
+            preds = torch.relu(model(batch))
+            ue = model.get_user_embeddings(batch)
+            took = AG.STATS["shared_qkv_forwards"] - before
+            loss = torch.nn.functional.mse_loss(preds, batch["targets"]) + 0.1 * contrastive_loss(ue, labels, 0.08)
+            loss.backward()
+        finally:
+            AG.SHARE_QKV = old
+        return loss.detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, took
+
+    l0, g0, t0 = step(False)
+    l1, g1, t1 = step(True)
+    assert t0 == 0 and t1 == 1  # the second history encode (the candidates and the user tower see other inputs)
+    assert torch.equal(l0, l1) and g0.keys() == g1.keys()
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    # an in-place change of the input between the two encodes: another version counter, no reuse
+    hx, hm = batch["user_features"]["history"]["title_emb"]
+    before = AG.STATS["shared_qkv_forwards"]
+    preds = model(batch)
+    hx.mul_(1.0)
+    model.get_user_embeddings(batch)
+    assert AG.STATS["shared_qkv_forwards"] == before
+    del preds
+    # input dropout > 0 (no shipped config): every encode sees its own dropped copy, no reuse
+    model.news_encoder.dropout.p = 0.5
+    before = AG.STATS["shared_qkv_forwards"]
+    preds = model(batch)
+    model.get_user_embeddings(batch)
+    assert AG.STATS["shared_qkv_forwards"] == before
+    model.news_encoder.dropout.p = 0.0

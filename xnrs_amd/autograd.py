@@ -81,7 +81,7 @@ LIVE_ROWS = os.environ.get("XNRS_BWD_LIVE_ROWS", "1") != "0"
 LIVE_ROWS_MAX_FRACTION = 0.9
 LIVE_ROWS_MIN = 4096  # token rows from which the live-row path pays for its index bookkeeping (tests lower it)
 #: how many training forwards took the live-row path (tests assert that the branch they mean to cover really ran)
-STATS = {"live_row_forwards": 0, "kv_row_forwards": 0}
+STATS = {"live_row_forwards": 0, "kv_row_forwards": 0, "shared_qkv_forwards": 0}
 #: K|V projection and dWk / dWv over the token rows of the non-empty news only (rides on the live-row path, exact;
 #: include/xnrs_hip.h: xnrs_row_lists).  XNRS_KV_ROWS=0 turns it off.
 KV_ROWS = os.environ.get("XNRS_KV_ROWS", "1") != "0"
@@ -89,6 +89,26 @@ KV_ROWS = os.environ.get("XNRS_KV_ROWS", "1") != "0"
 
 def _addr(t):
     return None if t is None else t.data_ptr()
+
+
+#: The reference's train step encodes the history twice (training.py:406 scores, :409 get_user_embeddings); with input
+#: dropout 0 (every shipped config) the two encodes differ only in their attention-dropout draws, so their Q|K|V images are
+#: the same numbers.  A training forward of an attention tower registers its saved blob and row lists here under the
+#: identity of everything the image depends on -- data pointer AND version counter of input, mask, ids and the six projection
+#: tensors -- and a second forward that finds a LIVE entry reads that image instead of projecting again (and reuses the row
+#: lists: no second host read).  Weak references: an entry dies with the first forward's graph.  Bitwise the same step.
+#: XNRS_SHARE_QKV=0 turns it off.
+SHARE_QKV = os.environ.get("XNRS_SHARE_QKV", "1") != "0"
+_QKV_IMAGES = {}
+
+
+def _ident(t):
+    return None if t is None else (t.data_ptr(), t._version, tuple(t.shape))
+
+
+def _qkv_key(cfg, x, m, ids, params):
+    return (cfg.n_seq, cfg.L, cfg.D, cfg.n_heads, cfg.A, cfg.E, cfg.pool_kind, cfg.has_head, x.device.index, _ident(x), _ident(m),
+            _ident(ids), tuple(_ident(p) for p in params[:6]))  # (_att_tensors order: wq, bq, wk, bk, wv, bv, wo, bo)
 
 
 class _SeqEncode(torch.autograd.Function):
@@ -114,7 +134,21 @@ class _SeqEncode(torch.autograd.Function):
         # bookkeeping with torch (one host sync for the count); skipped when few rows are masked.
         live = live_src = kv = kv_src = None
         n_live = n_kv = 0
-        if LIVE_ROWS and m is not None and cfg.pool_kind == hip.POOL_ADDITIVE and n * L >= LIVE_ROWS_MIN:
+        shared = None  # (blob of an earlier forward over the same input and projection weights, its row lists)
+        key = None
+        if SHARE_QKV and cfg.n_heads > 0:
+            key = _qkv_key(cfg, x, m, ids, params)
+            ent = _QKV_IMAGES.get(key)
+            if ent is not None:
+                blob = ent[0]()
+                if blob is None:
+                    del _QKV_IMAGES[key]
+                else:
+                    shared = (blob, ent[1])
+        if shared is not None:
+            live, live_src, n_live, kv, kv_src, n_kv = shared[1]
+            STATS["shared_qkv_forwards"] += 1
+        elif LIVE_ROWS and m is not None and cfg.pool_kind == hip.POOL_ADDITIVE and n * L >= LIVE_ROWS_MIN:
             lm = (m[ids.long()] if ids is not None else m).reshape(n, L).ne(0)
             news_live = lm.any(dim=1)
             # ONE host read for both counts (unmasked token rows, non-empty news); the lists are then sized without a sync
@@ -137,14 +171,25 @@ class _SeqEncode(torch.autograd.Function):
                     STATS["kv_row_forwards"] += 1
                     if ids is not None:
                         kv_src = (src_news[news_idx][:, None] * L + tok[None, :]).reshape(-1).to(torch.int32)
+        qkv_shared = None
+        if shared is not None:
+            qkv_shared = shared[0].data_ptr() + l.xnrs_seq_encoder_saved_qkv_offset(n, L, D, cfg.A, Eo, cfg.n_heads, cfg.pool_kind,
+                                                                                     int(cfg.has_head))
         lists = None
-        if live is not None:
-            lists = hip.RowLists(_addr(live), _addr(live_src), n_live, _addr(kv), _addr(kv_src), n_kv)
+        if live is not None or qkv_shared is not None:
+            lists = hip.RowLists(_addr(live), _addr(live_src), n_live, _addr(kv), _addr(kv_src), n_kv, qkv_shared)
         hip.check(l.xnrs_seq_encoder_fwd_train_rows(hip.ptr(x), hip.ptr(m), hip.ptr(ids), n, L, D, _ref(ap), cfg.pool_kind,
                                                     _ref(pp), _ref(hp), hip.ptr(y), hip.ptr(a), hip.ptr(hm), hip.ptr(saved),
                                                     nsaved, _ref(lists), hip.stream_ptr(dev)),
                   "xnrs_seq_encoder_fwd_train_rows")
         ctx.row_lists = (live, live_src, n_live, kv, kv_src, n_kv)
+        ctx.qkv_shared = qkv_shared
+        ctx.qkv_owner = shared[0] if shared is not None else None  # keeps the other forward's blob alive until our backward
+        if key is not None and shared is None:
+            import weakref
+            for k in [k for k, v in _QKV_IMAGES.items() if v[0]() is None]:
+                del _QKV_IMAGES[k]
+            _QKV_IMAGES[key] = (weakref.ref(saved), ctx.row_lists)
         ctx.fold = l.xnrs_train_fold_enabled()  # the saved blob is laid out by this decision (include/xnrs_hip.h)
         ctx.cfg = cfg
         ctx.nsaved = nsaved
@@ -193,8 +238,8 @@ class _SeqEncode(torch.autograd.Function):
         ws = hip.workspace(dev, nws)
         live, live_src, n_live, kv, kv_src, n_kv = ctx.row_lists  # the row lists built by the forward
         lists = None
-        if live is not None:
-            lists = hip.RowLists(_addr(live), _addr(live_src), n_live, _addr(kv), _addr(kv_src), n_kv)
+        if live is not None or ctx.qkv_shared is not None:
+            lists = hip.RowLists(_addr(live), _addr(live_src), n_live, _addr(kv), _addr(kv_src), n_kv, ctx.qkv_shared)
         hip.check(l.xnrs_seq_encoder_bwd_rows(hip.ptr(x), hip.ptr(m), hip.ptr(ids), n, L, D, _ref(ap), cfg.pool_kind, _ref(pp),
                                               _ref(hp), hip.ptr(saved), ctx.nsaved, hip.ptr(dy), hip.ptr(dx), _ref(ga),
                                               _ref(gp), _ref(gh), _ref(lists), hip.ptr(ws), nws,

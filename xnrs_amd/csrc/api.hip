@@ -233,7 +233,7 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
                    const xnrs_head_params* head, float* y, float* a_out, float* hm, int64_t chunk, void* ws,
                    size_t ws_bytes, hipStream_t stream, bool train = false, const int32_t* live_rows = nullptr,
                    const int32_t* live_src_rows = nullptr, int64_t n_live = 0, const int32_t* kv_rows = nullptr,
-                   const int32_t* kv_src_rows = nullptr, int64_t n_kv = 0) {
+                   const int32_t* kv_src_rows = nullptr, int64_t n_kv = 0, const float* qkv_shared = nullptr) {
   if (n_seq == 0) return XNRS_OK;
   if (n_seq < 0 || L <= 0 || D <= 0 || !x || !y) return XNRS_EINVAL;
   if (att) {
@@ -259,7 +259,9 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
   char* w = static_cast<char*>(ws);
   float* stats = (train && att) ? reinterpret_cast<float*>(w + p.off_stats) : nullptr;
   float* a_save = (train && additive) ? reinterpret_cast<float*>(w + p.off_a) : nullptr;
-  float* qkv = reinterpret_cast<float*>(w + p.off_qkv);
+  // (training) the Q|K|V image of another forward over the same input and weights: read it, project nothing (xnrs_row_lists)
+  const bool qkv_given = train && att && qkv_shared;
+  float* qkv = qkv_given ? const_cast<float*>(qkv_shared) : reinterpret_cast<float*>(w + p.off_qkv);
   float* o = reinterpret_cast<float*>(w + p.off_o);
   float* yb = reinterpret_cast<float*>(w + p.off_y);
   float* t = reinterpret_cast<float*>(w + p.off_t);
@@ -429,7 +431,9 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
       g.K = D;
       g.act = XNRS_ACT_NONE;
       const int dk = D / att->n_heads;
-      if (live) {  // K|V of every row (kvl: of the rows of the non-empty news), Q of the live rows only (dead rows = 0)
+      if (qkv_given) {
+        // nothing to project
+      } else if (live) {  // K|V of every row (kvl: of the rows of the non-empty news), Q of the live rows only (dead rows = 0)
         ProfScope ps(0, 2.0 * (kvl ? n_kv : rows) * 2.0 * D * D + 2.0 * n_live * (double)D * D, stream);
         g.W[0] = att->wk; g.W[1] = att->wv; g.W[2] = nullptr;
         g.Wp[0] = pk; g.Wp[1] = pv; g.Wp[2] = nullptr;
@@ -1312,6 +1316,13 @@ size_t xnrs_seq_encoder_saved_bytes(int64_t n_seq, int32_t L, int32_t D, int32_t
       .total;
 }
 
+size_t xnrs_seq_encoder_saved_qkv_offset(int64_t n_seq, int32_t L, int32_t D, int32_t A, int32_t E, int32_t n_heads,
+                                         int32_t pool_kind, int32_t has_head) {
+  const bool pooled = pool_kind != XNRS_POOL_NONE;
+  return make_plan(n_seq, L, D, A, E, n_heads > 0, pool_kind == XNRS_POOL_ADDITIVE, pooled && has_head, pooled, 0, true, n_heads)
+      .off_qkv;
+}
+
 int32_t xnrs_seq_encoder_fwd_train(const float* x, const float* m, const int32_t* ids, int64_t n_seq, int32_t L, int32_t D,
                                    const xnrs_mha_params* att, int32_t pool_kind, const xnrs_additive_params* pool,
                                    const xnrs_head_params* head, float* y, float* a_out, float* hm, void* saved,
@@ -1345,7 +1356,7 @@ int32_t xnrs_seq_encoder_fwd_train_rows(const float* x, const float* m, const in
   if (ids && ((r->live_rows && !r->live_src_rows) || (r->kv_rows && !r->kv_src_rows))) return XNRS_EINVAL;
   return seq_encode(x, m, ids, n_seq, L, D, att, pooled, pool_kind, pool, pooled ? head : nullptr, y, a_out, hm, 0, saved,
                     saved_bytes, (hipStream_t)stream, true, r->live_rows, r->live_src_rows, r->n_live, r->kv_rows,
-                    r->kv_src_rows, r->n_kv);
+                    r->kv_src_rows, r->n_kv, r->qkv_shared);
 }
 
 size_t xnrs_seq_encoder_bwd_workspace_bytes(int64_t n_seq, int32_t L, int32_t D, int32_t A, int32_t E, int32_t n_heads,
@@ -1408,7 +1419,7 @@ int32_t xnrs_seq_encoder_bwd_rows(const float* x, const float* m, const int32_t*
   const BwdPlan bp = make_bwd_plan(n_seq, L, D, A, E, nh, additive, head != nullptr, pooled);
   if (bp.total > ws_bytes || (bp.total > 0 && !ws)) return XNRS_EWORKSPACE;
   const char* sv = static_cast<const char*>(saved);
-  const float* qkv = reinterpret_cast<const float*>(sv + sp.off_qkv);
+  const float* qkv = (att && rl->qkv_shared) ? rl->qkv_shared : reinterpret_cast<const float*>(sv + sp.off_qkv);
   const float* o = reinterpret_cast<const float*>(sv + sp.off_o);
   const float* yatt = reinterpret_cast<const float*>(sv + sp.off_y);
   const float* t = reinterpret_cast<const float*>(sv + sp.off_t);

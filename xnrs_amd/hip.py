@@ -34,7 +34,7 @@ SYMBOLS = (
     "xnrs_infonce_saved_bytes", "xnrs_infonce_fwd", "xnrs_infonce_bwd", "xnrs_train_fold_enabled",
     "xnrs_fold_weights_workspace_bytes", "xnrs_fold_weights",
     "xnrs_text_encoder_compact_workspace_bytes", "xnrs_text_encoder_fwd_compact",
-    "xnrs_seq_encoder_fwd_train_rows", "xnrs_seq_encoder_bwd_rows",
+    "xnrs_seq_encoder_fwd_train_rows", "xnrs_seq_encoder_bwd_rows", "xnrs_seq_encoder_saved_qkv_offset",
 )
 POOL_NONE = -1
 PROFILE_STAGES = ("qkv_gemm", "attention_core", "out_gemm", "fc1_tanh_gemm", "pool", "head_gemms", "news_fused",
@@ -63,7 +63,7 @@ class HeadParams(C.Structure):
 class RowLists(C.Structure):
     """xnrs_row_lists: the unmasked token rows and the token rows of the non-empty news (include/xnrs_hip.h)."""
     _fields_ = [("live_rows", C.c_void_p), ("live_src_rows", C.c_void_p), ("n_live", C.c_int64),
-                ("kv_rows", C.c_void_p), ("kv_src_rows", C.c_void_p), ("n_kv", C.c_int64)]
+                ("kv_rows", C.c_void_p), ("kv_src_rows", C.c_void_p), ("n_kv", C.c_int64), ("qkv_shared", C.c_void_p)]
 
 
 class MhaGrads(C.Structure):
@@ -145,6 +145,8 @@ def lib():
     l.xnrs_seq_encoder_bwd_live.argtypes = [p, p, p, i64, i32, i32, C.POINTER(MhaParams), i32, C.POINTER(AdditiveParams),
                                             C.POINTER(HeadParams), p, sz, p, p, C.POINTER(MhaGrads), C.POINTER(AdditiveGrads),
                                             C.POINTER(HeadGrads), p, p, i64, p, sz, p]
+    l.xnrs_seq_encoder_saved_qkv_offset.restype = sz
+    l.xnrs_seq_encoder_saved_qkv_offset.argtypes = [i64, i32, i32, i32, i32, i32, i32, i32]
     l.xnrs_seq_encoder_fwd_train_rows.restype = i32
     l.xnrs_seq_encoder_fwd_train_rows.argtypes = [p, p, p, i64, i32, i32, C.POINTER(MhaParams), i32, C.POINTER(AdditiveParams),
                                                   C.POINTER(HeadParams), p, p, p, p, sz, C.POINTER(RowLists), p]
@@ -201,7 +203,7 @@ def lib():
     l.xnrs_fold_weights_workspace_bytes.argtypes = [i32, i32]
     l.xnrs_fold_weights.restype = i32
     l.xnrs_fold_weights.argtypes = [C.POINTER(MhaParams), C.POINTER(AdditiveParams), i32, p, p, p, sz, p]
-    if l.xnrs_abi_version() != 4:
+    if l.xnrs_abi_version() != 5:
         raise XnrsHipError("libxnrs_hip.so ABI version mismatch; rebuild it")
     _lib = l
     return l
