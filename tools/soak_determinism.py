@@ -38,8 +38,12 @@ tgt[:, 0] = 1
 
 
 def grads():
+    # the reference's step: scores, then the user embeddings of a second history encode (which reads the first one's Q|K|V
+    # image, autograd._QKV_IMAGES) feeding a second loss term
     m2.zero_grad(set_to_none=True)
-    torch.nn.functional.mse_loss(torch.relu(m2(batch)), tgt).backward()
+    loss = torch.nn.functional.mse_loss(torch.relu(m2(batch)), tgt)
+    loss = loss + 0.1 * m2.get_user_embeddings(batch).square().mean()
+    loss.backward()
     return [p.grad.clone() for p in m2.parameters() if p.grad is not None]
 
 
