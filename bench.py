@@ -393,45 +393,136 @@ def train_roofline(fn, dt):
             "stage_tflops": {k: (v[2] / (v[0] * 1e-3) / 1e12) for k, v in st.items() if v[0] > 0}}
 
 
-def train_step_extra(device, steps=5, warmup=2, model_name="NRMS", variants=True):
-    """The grad step of the reference (training.py:402-431) on the HIP path: NRMS at the shipped
-    config (batch 64, H=25, C=5, S=50, D=768, train-mode attention dropout 0.1), forward + relu/MSE +
-    lambda*InfoNCE on a second history encode + backward + Adam."""
-    w = dict(B=64, H=25, C=5, S=50, D=768, h=16, E=256, A=256)
-    model, _ = build_model(w, device, model_name=model_name)
-    model.train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
-    hist, cand = make_inputs(w, device, seed=7)
-    targets = torch.zeros(w["B"], w["C"], 1, device=device)
-    targets[:, 0] = 1.0
-    labels = torch.randint(0, 6, (w["B"],), device=device)
-    batch = {"user_features": {"history": {"title_emb": hist}, "other": {}}, "candidate_features": {"title_emb": cand}}
+TRAIN_W = dict(B=64, H=25, C=5, S=50, D=768, h=16, E=256, A=256)
+TRAIN_MODELS = {"nrms": "NRMS", "standard": "standard", "naml": "NAML"}
 
+
+def make_train_job(model_name, device, seed=7, dist_factory=None):
+    """Model, synthetic batch and the grad step of the reference (ContrastiveRankingTrainer._train_step,
+    training.py:402-431) IN THE REFERENCE'S CALL ORDER: preds = model(batch) -> relu/MSE (training.py:388-392); user
+    embeddings = model.get_user_embeddings(batch), i.e. a SECOND history encode (training.py:409, parent.py:49-81); InfoNCE
+    on them; backward; Adam.  What the library shares between the two encodes is its business and exact: the Q|K|V
+    projection and one dW product per projection for NRMS (the attention-dropout draws differ), the whole deterministic
+    encode for StandardRec / NAML (no dropout anywhere: bit-identical outputs; tests/test_hip_train_step.py).
+    dist_factory: None, or model -> (distributed module, ShardLayout, GradBucket, n_global) for the data-parallel job."""
     from xnrs_amd.losses import contrastive_loss as infonce  # fused HIP forward/backward (training.py:433-472)
+    w = TRAIN_W
+    name = TRAIN_MODELS.get(model_name, model_name)
+    model, _ = build_model(w, device, model_name=name)
+    model.train()
+    dist = dist_factory(model) if dist_factory is not None else None
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    B, H, C, S, D = w["B"], w["H"], w["C"], w["S"], w["D"]
+    hist, cand = make_inputs(w, device, seed=seed)
+    hfeat, cfeat = {"title_emb": hist}, {"title_emb": cand}
+    if name == "NAML":  # title + abstract token tensors, category / subcategory ids (naml.py:61-112)
+        gen = torch.Generator(device=device)
+        gen.manual_seed(seed + 1)
+        ah, ac = make_inputs(w, device, seed=seed + 2)
+        # an empty history slot is empty in every view (dataset.py:82-85)
+        slot = hist[1].reshape(B, H, S).ne(0).any(dim=2).to(torch.float32)
+        hfeat["abstract_emb"] = (ah[0] * slot[:, :, None, None], ah[1] * slot[:, :, None, None])
+        cfeat["abstract_emb"] = ac
+        for d_, n in ((hfeat, H), (cfeat, C)):
+            d_["category_index"] = torch.randint(1, 20, (B, n), generator=gen, device=device, dtype=torch.int32)
+            d_["subcategory_index"] = torch.randint(1, 301, (B, n), generator=gen, device=device, dtype=torch.int32)
+    targets = torch.zeros(B, C, 1, device=device)
+    targets[:, 0] = 1.0
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed + 1000)
+    labels = torch.randint(0, 6, (B,), device=device, generator=gen)
+    batch = {"user_features": {"history": hfeat, "other": {}}, "candidate_features": cfeat}
 
-    def fn():
-        opt.zero_grad()
+    def fn(step_opt=True):
+        if dist is not None:
+            dist[2].zero_grad()
+        else:
+            opt.zero_grad()
         preds = torch.relu(model(batch))
-        loss = torch.nn.functional.mse_loss(preds, targets) + 0.1 * infonce(model.get_user_embeddings(batch), labels, 0.08)
+        rec = torch.nn.functional.mse_loss(preds, targets)
+        ue = model.get_user_embeddings(batch)  # the reference's second history encode
+        ue = ue.reshape(ue.size(0), -1)
+        if dist is not None:  # two collectives, no host sync: [embedding | label bits] all-gather + flat gradient all-reduce
+            D_, layout, bucket, n_global = dist
+            ue_all, lab_all = D_.gather_embeddings_and_labels(ue, labels, layout)
+            loss = D_.global_train_loss(rec, B, n_global, infonce(ue_all, lab_all, 0.08), 0.1)
+        else:
+            loss = rec + 0.1 * infonce(ue, labels, 0.08)
         loss.backward()
-        opt.step()
+        if dist is not None:
+            dist[2].allreduce()
+        if step_opt:
+            opt.step()
         return loss
+    return model, opt, batch, targets, labels, fn
+
+
+def graph_train_step(model, fn, device, steps, warmup):
+    """The same grad step captured ONCE in a hipGraph (forward + losses + backward + Adam) and replayed: possible because
+    the step has no host synchronisation (row lists and their counts stay on the device).  Attention dropout draws a fresh
+    mask per replay through a device seed word incremented inside the captured step (ops.set_dropout_seed_word)."""
+    from xnrs_amd import ops
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=True)
+    word = torch.zeros(1, dtype=torch.int64, device=device)
+    ops.set_dropout_seed_word(word)
+    try:
+        def one():
+            word.add_(1)
+            opt.zero_grad(set_to_none=False)
+            loss = fn(step_opt=False)
+            opt.step()
+            return loss
+        for p in model.parameters():
+            if p.requires_grad:
+                p.grad = torch.zeros_like(p)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                one()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):  # (the warm-up stream: see tests/test_hip_train_step.py on AccumulateGrad streams)
+            loss = one()
+        dt = timed(g.replay, steps, warmup, False) / steps
+        return dict(ms=dt * 1e3, loss_finite=bool(torch.isfinite(loss).item()))
+    finally:
+        ops.set_dropout_seed_word(None)
+
+
+def train_step_extra(device, steps=5, warmup=2, model_name="NRMS", variants=True):
+    """The grad step of the reference (training.py:402-431) on the HIP path at the shipped config (batch 64, H=25, C=5,
+    S=50, D=768, train mode: NRMS attention dropout 0.1): see make_train_job."""
+    from xnrs_amd import autograd as AG
+    from xnrs_amd.losses import contrastive_loss as infonce
+    w = TRAIN_W
+    model, opt, batch, targets, labels, fn = make_train_job(model_name, device)
+    stats0 = dict(AG.STATS)
     dt = timed(fn, steps, warmup, False) / steps
-    out = dict(ms=dt * 1e3, impressions_per_s=w["B"] / dt, batch=w["B"], loss_finite=bool(torch.isfinite(fn()).item()))
+    per_step = {k: (AG.STATS[k] - stats0[k]) / (steps + warmup) for k in AG.STATS}
+    out = dict(ms=dt * 1e3, impressions_per_s=w["B"] / dt, batch=w["B"], loss_finite=bool(torch.isfinite(fn()).item()),
+               step="reference order: model(batch) + get_user_embeddings(batch) (two history encodes), MSE + 0.1 InfoNCE, backward, Adam",
+               host_syncs_in_step=0 if per_step["device_list_forwards"] > 0 or per_step["live_row_forwards"] == 0 else "one per encoder call",
+               per_step=per_step)
     assert out["loss_finite"], model_name
     out["roofline"] = train_roofline(fn, dt)
     if not variants:
         return out
-    # the same step with the empty history slots sharing one encoded representative (exact, DESIGN.md section 10.1)
-    model.news_encoder.skip_empty = True
     try:
-        dt2 = timed(fn, steps, warmup, False) / steps
-        out["skip_empty"] = dict(ms=dt2 * 1e3, impressions_per_s=w["B"] / dt2, loss_finite=bool(torch.isfinite(fn()).item()))
-    finally:
-        model.news_encoder.skip_empty = False
-
-    # one history encode feeding both the scores and the InfoNCE term (forward(..., return_embeddings=True) instead of
-    # the reference's second encode at training.py:409; in train mode the two uses then share one dropout draw)
+        out["hipgraph_replay"] = graph_train_step(model, fn, device, steps, warmup)
+    except Exception as e:  # noqa: BLE001  (reported, never hidden)
+        out["hipgraph_replay"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if TRAIN_MODELS.get(model_name, model_name) != "NRMS":
+        # what the sharing of the deterministic second encode saves: the same step computing both encodes
+        old, AG.SHARE_OUTPUTS = AG.SHARE_OUTPUTS, False
+        try:
+            dt2 = timed(fn, steps, warmup, False) / steps
+            out["both_encodes_computed"] = dict(ms=dt2 * 1e3, impressions_per_s=w["B"] / dt2)
+        finally:
+            AG.SHARE_OUTPUTS = old
+        return out
+    # NOT the reference's step (labelled extra): one history encode feeding both the scores and the InfoNCE term
+    # (forward(..., return_embeddings=True) instead of the second encode at training.py:409 -- one dropout draw instead of two)
     def fn_shared():
         opt.zero_grad()
         r, u, _ = model(batch, return_embeddings=True)
@@ -440,14 +531,52 @@ def train_step_extra(device, steps=5, warmup=2, model_name="NRMS", variants=True
         opt.step()
         return loss
     dt3 = timed(fn_shared, steps, warmup, False) / steps
-    out["shared_history_encode"] = dict(ms=dt3 * 1e3, impressions_per_s=w["B"] / dt3)
-    model.news_encoder.skip_empty = True
+    out["one_history_encode_NOT_the_reference_step"] = dict(ms=dt3 * 1e3, impressions_per_s=w["B"] / dt3)
+    # the round-3 step for comparison: host-built row lists (one .tolist() per encoder call), one dW product per encode
+    old = (AG.DEVICE_LISTS, AG.MERGE_DW)
+    AG.DEVICE_LISTS, AG.MERGE_DW = False, False
     try:
-        dt4 = timed(fn_shared, steps, warmup, False) / steps
-        out["shared_history_encode+skip_empty"] = dict(ms=dt4 * 1e3, impressions_per_s=w["B"] / dt4,
-                                                       loss_finite=bool(torch.isfinite(fn_shared()).item()))
+        dt4 = timed(fn, steps, warmup, False) / steps
+        out["round3_path_host_lists_unmerged_dw"] = dict(ms=dt4 * 1e3, impressions_per_s=w["B"] / dt4)
     finally:
-        model.news_encoder.skip_empty = False
+        AG.DEVICE_LISTS, AG.MERGE_DW = old
+    return out
+
+
+def ig_step_extra(device, n_steps=40):
+    """The ONE timing the reference publishes for this code: integrated-gradient steps per second --
+    per step a forward of one impression (H history news, 1 candidate, S=50, D=768) and autograd.grad(score, history
+    tokens), Explainer.explain_score_in_batch (xnrs/explain.py:144-166), through the HIP input-gradient path.  Reference
+    figures (an unnamed CUDA device, context only): 316.7 it/s (9-news history), 177.4 it/s (one MIND session)."""
+    out = {"reference_unnamed_cuda": {"H9": 316.70, "mind_session": 177.41, "source": "BASELINE.md section 1"}}
+    for name in ("standard", "NRMS"):
+        for H in (9, 25):
+            w = dict(B=1, H=H, C=1, S=50, D=768, h=16, E=256, A=256)
+            model, _ = build_model(w, device, model_name=name)
+            (hx, hm), (cx, cm) = make_inputs(w, device, seed=50 + H, full_history=True)
+            hx = hx.clone().requires_grad_()
+            hm = hm.clone().requires_grad_()   # explain.py:152 marks the mask too
+            cx = cx.clone().requires_grad_()
+            cm = cm.clone().requires_grad_()
+
+            def run(n):
+                c, _ = model.news_encoder((cx, cm))
+                da = 1.0 / n
+                grads = []
+                for a in torch.arange(da, 1 + da, da)[:n]:
+                    ga = a * hx
+                    ha, ham = model.news_encoder((ga, hm))
+                    ua = model.user_encoder.forward(inpt=(ha, ham))
+                    sa = torch.relu(model.rec_model(ua, c))
+                    grads.append(torch.autograd.grad(sa, ga)[0])
+                return torch.cat(grads)
+            run(5)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            g = run(n_steps)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out[f"{name}_H{H}"] = dict(it_per_s=n_steps / dt, ms_per_it=dt / n_steps * 1e3, grads_finite=bool(torch.isfinite(g).all().item()))
     return out
 
 
@@ -714,57 +843,31 @@ def latency_extra(device, reps=50):
 
 
 def train_scaling(args, device, rank, world, dist_on):
-    """--train: the grad step of the reference (training.py:402-431) as a data-parallel job.  Weak scaling: every
-    rank owns 64 impressions (mind_small_NRMS.yml batch size; mind_small_CL.yml uses 16 -- too little work per GPU,
-    SURVEY.md section 8e), weights replicated.  Per step: local forward (one history encode feeding scores and user
-    embeddings), relu/MSE on the local impressions, InfoNCE over the GLOBAL batch (differentiable all-gather of the
-    user embeddings + labels), backward, one flat SUM all-reduce of the gradients, Adam."""
+    """--train: the grad step of the reference (training.py:402-431, in its call order: make_train_job) as a data-parallel
+    job.  Weak scaling: every rank owns 64 impressions (mind_small_NRMS.yml batch size; mind_small_CL.yml uses 16 -- too
+    little work per GPU), weights replicated.  Per step: local forward + second history encode,
+    relu/MSE on the local impressions, InfoNCE over the GLOBAL batch (differentiable all-gather of the user embeddings +
+    labels), backward, one flat SUM all-reduce of the gradients, Adam."""
     from xnrs_amd import distributed as D
-    from xnrs_amd.losses import contrastive_loss as infonce
-    w = dict(B=64, H=25, C=5, S=50, D=768, h=16, E=256, A=256)
-    model, _ = build_model(w, device, model_name="NRMS" if args.train == "nrms" else "standard")
-    model.train()
-    if dist_on:
-        D.broadcast_parameters(model)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
-    hist, cand = make_inputs(w, device, seed=2000 + rank)
-    targets = torch.zeros(w["B"], w["C"], 1, device=device)
-    targets[:, 0] = 1.0
-    gen = torch.Generator(device=device)
-    gen.manual_seed(3000 + rank)
-    labels = torch.randint(0, 6, (w["B"],), device=device, generator=gen)
-    batch = {"user_features": {"history": {"title_emb": hist}, "other": {}}, "candidate_features": {"title_emb": cand}}
+    w = TRAIN_W
     n_global = w["B"] * (world if dist_on else 1)
-    # once per run: the shard layout (fixed per-rank batch -> no communication) and the persistent gradient bucket
-    layout = D.ShardLayout.uniform(w["B"]) if dist_on else None
-    bucket = D.GradBucket(model.parameters()) if dist_on else None
-
-    def fn():
-        if dist_on:
-            bucket.zero_grad()
-        else:
-            opt.zero_grad()
-        r, u, _ = model(batch, return_embeddings=True)
-        rec = torch.nn.functional.mse_loss(torch.relu(r), targets)
-        if dist_on:  # two collectives, no host sync: [embedding | label bits] all-gather + flat gradient all-reduce
-            ue_all, lab_all = D.gather_embeddings_and_labels(u.squeeze(1), labels, layout)
-            loss = D.global_train_loss(rec, w["B"], n_global, infonce(ue_all, lab_all, 0.08), 0.1)
-        else:
-            loss = rec + 0.1 * infonce(u.squeeze(1), labels, 0.08)
-        loss.backward()
-        if dist_on:
-            bucket.allreduce()
-        opt.step()
-        return loss
+    # once per run: weights broadcast from rank 0, the shard layout (fixed per-rank batch -> no communication) and the
+    # persistent gradient bucket
+    def factory(model):
+        D.broadcast_parameters(model)
+        return (D, D.ShardLayout.uniform(w["B"]), D.GradBucket(model.parameters()), n_global)
+    model, opt, batch, targets, labels, fn = make_train_job(args.train, device, seed=2000 + rank,
+                                                            dist_factory=factory if dist_on else None)
     dt = timed(fn, args.steps, args.warmup, dist_on)
     n_gpus = world if dist_on else 1
     roof = train_roofline(fn, dt / args.steps)  # every rank runs the profiled step (it contains the collectives)
-    return {"roofline": roof, "metric": "train impressions/sec (forward + loss + backward + gradient all-reduce + Adam)",
+    return {"roofline": roof, "metric": "train impressions/sec (forward + second history encode + loss + backward + gradient all-reduce + Adam)",
             "value": n_global * args.steps / dt, "unit": "impressions/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": GEMM_MODES[args.gemm_mode][0], "data": "synthetic",
-            "config": {"workload": f"{args.train} grad step, 64 impressions per GPU (H=25, C=5, S=50, D=768), global in-batch "
-                                   "InfoNCE (lambda 0.1, tau 0.08), attention dropout 0.1",
+            "vs_baseline": None, "dtype": GEMM_MODES[args.gemm_mode][0], "data": "synthetic", "build_id": hip.build_id(),
+            "config": {"workload": f"{args.train} grad step in the reference's call order (model(batch) + get_user_embeddings(batch): "
+                                   "two history encodes, training.py:402-431), 64 impressions per GPU (H=25, C=5, S=50, D=768), global "
+                                   "in-batch InfoNCE (lambda 0.1, tau 0.08), train mode (NRMS: attention dropout 0.1)",
                        "parallelism": f"impressions sharded over {n_gpus} GPU(s); per step ONE all-gather of (64, 256+1) [user "
                                       "embedding | label bits] + ONE flat fp32 gradient all-reduce in a persistent bucket, no "
                                       "host sync"},
@@ -781,7 +884,7 @@ def main():
     ap.add_argument("--gemm-mode", type=int, default=0, choices=(0, 1, 2),
                     help="arithmetic of the forward GEMMs for the HEADLINE line: 0 exact fp32 MFMA (default), "
                          "1 bf16x3 split, 2 bf16x2 split; the default run reports modes 1 and 2 under extra")
-    ap.add_argument("--train", choices=("nrms", "standard"), default=None,
+    ap.add_argument("--train", choices=("nrms", "standard", "naml"), default=None,
                     help="time the data-parallel GRAD step instead (BASELINE configs[3]: impressions sharded over the "
                          "ranks, global in-batch InfoNCE through a differentiable all-gather, one flat RCCL gradient "
                          "all-reduce); prints its own JSON line")
@@ -892,6 +995,8 @@ def main():
             "vs_baseline": None,
             "dtype": mode_name,
             "data": "synthetic",
+            "build_id": hip.build_id(),  # hash of the sources the measured binary was built from (= hip.tree_build_id())
+            "build_is_tree": hip.build_id() == hip.tree_build_id(),
             "config": {"workload": "NRMS full user+news encode + 5-candidate dot scoring "
                                    "(BASELINE configs[2]; token shape of config/mind_small_NRMS.yml)",
                        "batch_impressions_per_gpu": w["B"], "history": w["H"], "candidates": w["C"],
@@ -980,8 +1085,10 @@ def main():
                     out["extra"]["per_token_out_projection"] = unfolded_extra(model, hist, cand, args.steps, scores)
                 if args.gemm_mode == 0:
                     out["extra"]["gemm_modes"] = gemm_modes_extra(model, hist, cand, args.steps, scores, cpu_sample)
-            out["extra"]["nrms_train_step_B64"] = train_step_extra(device)
+            out["extra"]["nrms_train_step_B64"] = train_step_extra(device, model_name="nrms")
             out["extra"]["standard_train_step_B64"] = train_step_extra(device, model_name="standard")
+            out["extra"]["naml_train_step_B64"] = train_step_extra(device, model_name="naml")
+            out["extra"]["ig_step"] = ig_step_extra(device)
             out["extra"]["eval_epoch"] = eval_epoch_extra(device)
             out["extra"]["store_file_to_hbm"] = store_upload_extra(device)
         assert torch.isfinite(scores).all()

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define XNRS_ABI_VERSION 5
+#define XNRS_ABI_VERSION 6
 
 #define XNRS_OK 0
 #define XNRS_EINVAL (-1)     /* bad shape / NULL pointer */
@@ -56,6 +56,11 @@ typedef struct {
   int32_t scaled;   /* 1: scores / sqrt(d_k) (layers.py:139-140) */
   float dropout_p;  /* attention-probability dropout (layers.py:117,148); 0 in eval mode */
   uint64_t seed;    /* counter-based RNG seed for dropout; ignored when dropout_p == 0 */
+  /* ABI 6, optional: a DEVICE word added to `seed` by the kernels (forward and backward read it; the caller must not change
+   * it between a training forward and its backward).  A grad step captured in a hipGraph bakes `seed` into the graph; with
+   * this word -- incremented by the caller inside the captured step -- every replay draws a fresh attention-dropout mask
+   * (layers.py:148 draws one per call).  NULL: seed alone. */
+  const uint64_t *seed_dev;
 } xnrs_mha_params;
 
 /* layers.AdditiveAttention parameters (layers.py:42-45): fc1 Linear(D,A), fc2 Linear(A,1).
@@ -82,6 +87,9 @@ typedef struct {
 } xnrs_head_params;
 
 int32_t xnrs_abi_version(void);
+/* Hash of the sources this binary was built from (every .hip file of xnrs_amd/csrc, kernels.h, this header; the Makefile computes
+ * it): lets a reader tell the measured binary from the tree without a rebuild (tests/test_abi.py, bench.py). */
+const char *xnrs_build_id(void);
 const char *xnrs_error_string(int32_t code);
 
 /* ---- nn.Linear (layers.py:60,128-130,154; news_encoding.py:27-31) --------------------------
@@ -267,7 +275,35 @@ typedef struct {
    * gradients).  Identical results, bit for bit.  The caller keeps the other blob alive until this forward's backward
    * has run.  NULL: project as usual. */
   const float *qkv_shared;
+  /* ABI 6, optional: the two counts as DEVICE scalars, int64 counts_dev[2] = {n_live, n_kv} (xnrs_build_row_lists writes
+   * them).  n_live / n_kv above are then only the capacities of the lists (n_seq * L); every product over a list reads
+   * its row count on the device, so the caller never reads the counts back: no host synchronisation in the grad step, and
+   * its launch sequence does not depend on the data (hipGraph-capturable).  fp32 GEMM mode, 16-byte aligned operands and
+   * D, A multiples of 4 (XNRS_EUNSUPPORTED otherwise: pass host counts). */
+  const int64_t *counts_dev;
+  /* ABI 6, optional, backward only: ONE weight-gradient product per projection for two backward calls over the same
+   * Q|K|V image (qkv_shared above: the reference's two history encodes, training.py:406,409) --
+   *   dW = (dQKV_1 + dQKV_2)^T . X   instead of   dQKV_1^T . X + dQKV_2^T . X   (layers.py:128-130 under autograd).
+   * dqkv_image: caller-owned [n_seq*L, 3D] fp32.  dqkv_mode XNRS_DQKV_DEFER: this call leaves its dQ|dK|dV there and
+   * computes NO gradient of wq/bq/wk/bk/wv/bv (and no input gradient); XNRS_DQKV_MERGE: this call ADDS its dQ|dK|dV to
+   * the image and computes those gradients from the sum.  Both calls must pass the same row lists.  Rows of all-masked
+   * sequences / masked queries that the lists never reach may stay unwritten. */
+  float *dqkv_image;
+  int32_t dqkv_mode;
 } xnrs_row_lists;
+#define XNRS_DQKV_OWN 0
+#define XNRS_DQKV_DEFER 1
+#define XNRS_DQKV_MERGE 2
+
+/* The row lists of xnrs_row_lists built on the device from the mask (m: (n_seq, L) fp32, or the table's mask with ids):
+ * live_rows / kv_rows: int32 [n_seq * L] each (capacity; the first counts[0] / counts[1] entries are written, in row
+ * order -- what torch.nonzero gives); live_src_rows / kv_src_rows: the same tokens' rows in the table (required with ids,
+ * NULL otherwise); counts: int64 [2] = {n_live, n_kv}.  ws: xnrs_row_lists_workspace_bytes(n_seq).  Two short launches,
+ * no host synchronisation.  A token is live when its mask value is != 0 (as the host bookkeeping had it). */
+size_t xnrs_row_lists_workspace_bytes(int64_t n_seq);
+int32_t xnrs_build_row_lists(const float *m, const int32_t *ids, int64_t n_seq, int32_t L, int32_t *live_rows,
+                             int32_t *live_src_rows, int32_t *kv_rows, int32_t *kv_src_rows, int64_t *counts, void *ws,
+                             size_t ws_bytes, void *stream);
 /* byte offset of the Q|K|V image inside the saved blob of a training forward with these shapes (0 without attention) */
 size_t xnrs_seq_encoder_saved_qkv_offset(int64_t n_seq, int32_t L, int32_t D, int32_t A, int32_t E, int32_t n_heads,
                                          int32_t pool_kind, int32_t has_head);

@@ -35,9 +35,18 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_error_strings():
     l = hip.lib()
-    assert l.xnrs_abi_version() == 5
+    import re
+    want = int(re.search(r"#define XNRS_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "xnrs_hip.h")).read()).group(1))
+    assert l.xnrs_abi_version() == want == 6
     assert b"divisible" in l.xnrs_error_string(-2)
     assert l.xnrs_error_string(0) == b"ok"
+
+
+def test_binary_was_built_from_the_sources_in_this_tree():
+    """xnrs_build_id() = hash of csrc/*.hip + kernels.h + include/xnrs_hip.h at build time (csrc/Makefile); it must equal
+    the hash of those files NOW -- a measured binary that is not the tree's fails here, without a rebuild."""
+    assert hip.build_id() == hip.tree_build_id(), "libxnrs_hip.so is stale: run __graft_entry__.build()"
+    assert len(hip.build_id()) == 16
 
 
 def test_workspace_queries_are_pure_host_calls():

@@ -662,7 +662,9 @@ def test_second_history_encode_reuses_the_first_projection():
 
     def step(share):
         old, AG.SHARE_QKV = AG.SHARE_QKV, share
-        try:
+        old_merge, AG.MERGE_DW = AG.MERGE_DW, False  # (the merged dW product changes the summation order: tested in
+        old_out, AG.SHARE_OUTPUTS = AG.SHARE_OUTPUTS, False  # tests/test_hip_train_step.py; and with dropout 0 the whole
+        try:                                                  # second encode would be shared: here the projection alone)
             model.zero_grad(set_to_none=True)
             before = AG.STATS["shared_qkv_forwards"]
             preds = torch.relu(model(batch))
@@ -672,6 +674,8 @@ def test_second_history_encode_reuses_the_first_projection():
             loss.backward()
         finally:
             AG.SHARE_QKV = old
+            AG.MERGE_DW = old_merge
+            AG.SHARE_OUTPUTS = old_out
         return loss.detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, took
 
     l0, g0, t0 = step(False)
@@ -681,6 +685,7 @@ def test_second_history_encode_reuses_the_first_projection():
     for k in g0:
         assert torch.equal(g0[k], g1[k]), k
     # an in-place change of the input between the two encodes: another version counter, no reuse
+    AG.SHARE_OUTPUTS = False
     hx, hm = batch["user_features"]["history"]["title_emb"]
     before = AG.STATS["shared_qkv_forwards"]
     preds = model(batch)
@@ -695,3 +700,4 @@ def test_second_history_encode_reuses_the_first_projection():
     model.get_user_embeddings(batch)
     assert AG.STATS["shared_qkv_forwards"] == before
     model.news_encoder.dropout.p = 0.0
+    AG.SHARE_OUTPUTS = True

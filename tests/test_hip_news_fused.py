@@ -205,3 +205,46 @@ def test_fold_cache_is_bitwise_neutral_and_follows_weight_updates(shape):
         finally:
             hip.FOLD_CACHE = True
         assert torch.equal(y_new, y_new_plain) and not torch.equal(y_new, y_cached)
+
+
+def test_fold_cache_and_writes_through_dot_data():
+    """torch gives `p.data` its own version counter, so a write through it is invisible to the cache's fingerprint: after such
+    a write the caller calls hip.invalidate_fold_cache() (xnrs_amd.distributed.broadcast_parameters does, and writes through
+    p.detach(), which shares the counter).  Also: a model rebuilt at recycled addresses can never hit another model's entry
+    (the entry holds weak references to the source tensors and compares them with `is`)."""
+    S, D, h = 50, 768, 16
+    enc, _ = build(S, D, h, 64, 4252)
+    x, m = synth.token_block(synth.rng_for(4253), 1, 64, S, D, min_len=1, full_pad_prob=0.1)
+    x, m = x.to(DEV), m.to(DEV)
+    with torch.no_grad():
+        y0, _ = enc((x, m))
+        new = enc.att.out.weight.detach() * 1.5
+        enc.att.out.weight.data.copy_(new)  # NOT seen by the version counter ...
+        hip.invalidate_fold_cache()         # ... so the caller says so
+        y1, _ = enc((x, m))
+        hip.FOLD_CACHE = False
+        try:
+            y1_plain, _ = enc((x, m))
+        finally:
+            hip.FOLD_CACHE = True
+        assert torch.equal(y1, y1_plain) and not torch.equal(y1, y0)
+        # a write through p.detach() (what broadcast_parameters does) moves the parameter's own counter: no call needed
+        v = enc.pooler.fc1.weight._version
+        enc.pooler.fc1.weight.detach().mul_(0.5)
+        assert enc.pooler.fc1.weight._version == v + 1
+        y2, _ = enc((x, m))
+        hip.FOLD_CACHE = False
+        try:
+            y2_plain, _ = enc((x, m))
+        finally:
+            hip.FOLD_CACHE = True
+        assert torch.equal(y2, y2_plain) and not torch.equal(y2, y1)
+        # an entry whose source tensors are gone is never served to another module
+        key = (id(enc.att), id(enc.pooler))
+        refs = hip._fold_cache[key][0]
+        assert all(r is None or r() is not None for r in refs)
+        entry = hip._fold_cache[key]
+        fake = (tuple((lambda: None) if r is not None else None for r in refs),) + entry[1:]
+        hip._fold_cache[key] = fake  # what a dead weakref returns
+        y3, _ = enc((x, m))
+        assert torch.equal(y3, y2) and hip._fold_cache[key] is not fake  # rebuilt, not served

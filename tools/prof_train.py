@@ -11,5 +11,5 @@ import bench  # noqa: E402
 
 dev = torch.device("cuda", 0)
 r = bench.train_step_extra(dev, steps=int(sys.argv[1]) if len(sys.argv) > 1 else 3, warmup=1,
-                           model_name=sys.argv[2] if len(sys.argv) > 2 else "NRMS", variants=False)
+                           model_name=sys.argv[2] if len(sys.argv) > 2 else "nrms", variants=False)
 print(r)

@@ -136,6 +136,26 @@ struct ProfScope {
     if (_e != hipSuccess) return hip_rc(_e); \
   } while (0)
 
+// a row count for the launch timer's FLOP figure: the host value, or -- counts on the device, timer on for this stage --
+// read back (the timer is a measurement aid that synchronises anyway; no read happens while it is off)
+int64_t prof_count(int stage, const int64_t* cnt, int which, int64_t host_value, hipStream_t stream) {
+  if (!cnt || !((g_prof_mask >> stage) & 1u)) return host_value;
+  int64_t v = host_value;
+  if (hipStreamSynchronize(stream) != hipSuccess) return host_value;
+  if (hipMemcpy(&v, cnt + which, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return host_value;
+  return v;
+}
+
+// can every product over a device-counted row list run on the kernels that read their row count on the device?
+// (GemmArgs::m_dev: the fp32 buffer-load forward kernels; GemmArgs::k_dev: any dW kernel)
+bool device_counts_ok(const float* x, int D, int A, const xnrs_mha_params* att, const xnrs_additive_params* pool) {
+  auto al16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (!knobs().gemm_buf || gemm_mode() != 0 || D % 4 != 0 || D < 4 || (A > 0 && A % 4 != 0)) return false;
+  if (!al16(x) || (pool && !al16(pool->w1))) return false;
+  if (att && !(al16(att->wq) && al16(att->wk) && al16(att->wv) && al16(att->wo))) return false;
+  return (int64_t)D * D * 4 <= (1ll << 30) && (int64_t)A * D * 4 <= (1ll << 30);
+}
+
 GemmArgs gemm1(const float* A, const int32_t* ids, int gS, int64_t lda, const float* W, const float* b, float* C,
                int64_t ldc, int64_t M, int N, int K, int act, const unsigned short* planes = nullptr) {
   GemmArgs g{};
@@ -231,9 +251,16 @@ hipError_t pooled_out_projection(const float* po, const float* s, const xnrs_mha
 int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n_seq, int L, int D,
                    const xnrs_mha_params* att, bool pooled, int pool_kind, const xnrs_additive_params* pool,
                    const xnrs_head_params* head, float* y, float* a_out, float* hm, int64_t chunk, void* ws,
-                   size_t ws_bytes, hipStream_t stream, bool train = false, const int32_t* live_rows = nullptr,
-                   const int32_t* live_src_rows = nullptr, int64_t n_live = 0, const int32_t* kv_rows = nullptr,
-                   const int32_t* kv_src_rows = nullptr, int64_t n_kv = 0, const float* qkv_shared = nullptr) {
+                   size_t ws_bytes, hipStream_t stream, bool train = false, const xnrs_row_lists* rl = nullptr) {
+  const xnrs_row_lists no_lists{};
+  if (!rl) rl = &no_lists;
+  const int32_t *live_rows = rl->live_rows, *live_src_rows = rl->live_src_rows, *kv_rows = rl->kv_rows,
+                *kv_src_rows = rl->kv_src_rows;
+  const float* qkv_shared = rl->qkv_shared;
+  // counts on the device (xnrs_row_lists::counts_dev): the list lengths below are then CAPACITIES (every row), the
+  // products over a list read their row count on the device (GemmArgs::m_dev)
+  const int64_t* cnt = rl->counts_dev;
+  const int64_t n_live = cnt ? n_seq * L : rl->n_live, n_kv = cnt ? n_seq * L : rl->n_kv;
   if (n_seq == 0) return XNRS_OK;
   if (n_seq < 0 || L <= 0 || D <= 0 || !x || !y) return XNRS_EINVAL;
   if (att) {
@@ -276,13 +303,14 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
   // exactly as if the rows had been computed and then multiplied by the zero weight.
   // An attention-FREE additive tower (StandardRec, NAML's views) takes the same list for its one row-parallel product:
   // fc1 runs over the live token rows of x, T of the masked rows is zero.
-  const bool live = train && additive && m && live_rows && n_live >= 0 && n_live < n_seq * L &&
+  const bool live = train && additive && m && live_rows && (cnt || (n_live >= 0 && n_live < n_seq * L)) &&
                     !(ids && !live_src_rows);
+  if (cnt && live && !device_counts_ok(x, D, A, att, pool)) return XNRS_EUNSUPPORTED;
   const int32_t* lvx = live ? (ids ? live_src_rows : live_rows) : nullptr;  // rows of x (table rows with ids)
   // ... and K|V over the token rows of the NON-EMPTY news only (kv_rows, optional, exact): the keys and values of a news
   // are read by that news' own queries alone, and an all-masked news has no live query, so its K and V rows (zeroed
   // here: its attention rows then come out as finite zeros) reach neither the output nor a gradient.
-  const bool kvl = live && kv_rows && n_kv >= 0 && n_kv < n_seq * L && !(ids && !kv_src_rows);
+  const bool kvl = live && kv_rows && (cnt || (n_kv >= 0 && n_kv < n_seq * L)) && !(ids && !kv_src_rows);
   const int32_t* kvx = kvl ? (ids ? kv_src_rows : kv_rows) : nullptr;
 
   // Short sequences go through the fused kernel (below); everything else folds the out-projection behind the pooling.
@@ -434,7 +462,8 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
       if (qkv_given) {
         // nothing to project
       } else if (live) {  // K|V of every row (kvl: of the rows of the non-empty news), Q of the live rows only (dead rows = 0)
-        ProfScope ps(0, 2.0 * (kvl ? n_kv : rows) * 2.0 * D * D + 2.0 * n_live * (double)D * D, stream);
+        const double nl = (double)prof_count(0, cnt, 0, n_live, stream), nkv = (double)prof_count(0, cnt, 1, n_kv, stream);
+        ProfScope ps(0, 2.0 * (kvl ? nkv : rows) * 2.0 * D * D + 2.0 * nl * (double)D * D, stream);
         g.W[0] = att->wk; g.W[1] = att->wv; g.W[2] = nullptr;
         g.Wp[0] = pk; g.Wp[1] = pv; g.Wp[2] = nullptr;
         g.bias[0] = att->bk; g.bias[1] = att->bv; g.bias[2] = nullptr;
@@ -447,6 +476,8 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
           g.c_scatter = 1;
           g.c_scatter_ids = kv_rows;
           g.M = n_kv;
+          g.m_dev = cnt ? cnt + 1 : nullptr;
+          g.m_fill_hint = 0.6f;
           if (n_kv > 0) XNRS_TRY(launch_gemm_f32(g, stream));
         } else {
           XNRS_TRY(launch_gemm_f32(g, stream));
@@ -456,6 +487,8 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
           GemmArgs q = gemm1(cx, lvx, 1, D, att->wq, att->bq, qkv, 3 * (int64_t)D, n_live, D, D, XNRS_ACT_NONE, pq);
           q.c_scatter = 1;
           q.c_scatter_ids = live_rows;
+          q.m_dev = cnt;
+          q.m_fill_hint = 0.4f;
           XNRS_TRY(launch_gemm_f32(q, stream));
         }
       } else {
@@ -484,6 +517,7 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
       ma.scaled = att->scaled;
       ma.dropout_p = att->dropout_p;
       ma.seed = att->seed + (uint64_t)c0 * 0x9E3779B97F4A7C15ull;
+      ma.seed_dev = att->seed_dev;
       ma.stats = stats;
       ma.skip_dead = live ? 1 : 0;  // an all-masked news: zeros instead of attention over keys nobody weights (kernels.h)
       {
@@ -495,11 +529,13 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
       if (fold) {
         dst = o;  // the pooler works on the O rows (fold_out_projection); masked rows of O are finite and carry weight 0
       } else if (live) {
-        ProfScope ps(2, 2.0 * n_live * (double)D * D, stream);
+        ProfScope ps(2, 2.0 * (double)prof_count(2, cnt, 0, n_live, stream) * (double)D * D, stream);
         XNRS_TRY(hipMemsetAsync(dst, 0, (size_t)rows * D * sizeof(float), stream));
         if (n_live > 0) {
           GemmArgs og = gemm1(o, live_rows, 1, D, att->wo, att->bo, dst, D, n_live, D, D, XNRS_ACT_NONE, po);
           og.c_scatter = 1;
+          og.m_dev = cnt;
+          og.m_fill_hint = 0.4f;
           XNRS_TRY(launch_gemm_f32(og, stream));
         }
       } else {
@@ -515,12 +551,14 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
     float* hm_dst = hm ? hm + c0 : nullptr;
     if (additive) {
       if (live) {  // with attention seq is the dense attention output; without, the rows of x (table rows with ids: lvx)
-        ProfScope ps(3, 2.0 * n_live * (double)D * A, stream);
+        ProfScope ps(3, 2.0 * (double)prof_count(3, cnt, 0, n_live, stream) * (double)D * A, stream);
         XNRS_TRY(hipMemsetAsync(t, 0, (size_t)rows * A * sizeof(float), stream));
         if (n_live > 0) {
           GemmArgs fg = gemm1(seq, att ? live_rows : lvx, 1, D, fc1_w, fc1_b, t, A, n_live, A, D, XNRS_ACT_TANH, p1);
           fg.c_scatter = 1;
           fg.c_scatter_ids = live_rows;
+          fg.m_dev = cnt;
+          fg.m_fill_hint = 0.4f;
           XNRS_TRY(launch_gemm_f32(fg, stream));
         }
       } else {
@@ -594,6 +632,25 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
 extern "C" {
 
 int32_t xnrs_abi_version(void) { return XNRS_ABI_VERSION; }
+
+#ifndef XNRS_BUILD_ID
+#define XNRS_BUILD_ID "unknown"
+#endif
+const char* xnrs_build_id(void) { return XNRS_BUILD_ID; }
+
+size_t xnrs_row_lists_workspace_bytes(int64_t n_seq) { return n_seq > 0 ? align_up((size_t)n_seq * sizeof(int32_t)) : 0; }
+
+int32_t xnrs_build_row_lists(const float* m, const int32_t* ids, int64_t n_seq, int32_t L, int32_t* live_rows,
+                             int32_t* live_src_rows, int32_t* kv_rows, int32_t* kv_src_rows, int64_t* counts, void* ws,
+                             size_t ws_bytes, void* stream) {
+  if (n_seq < 0 || L <= 0 || !m || !live_rows || !kv_rows || !counts) return XNRS_EINVAL;
+  if (ids && (!live_src_rows || !kv_src_rows)) return XNRS_EINVAL;  // a gathered table needs the tokens' table rows
+  if (n_seq * (int64_t)L > 0x7fffffffLL) return XNRS_EUNSUPPORTED;   // int32 row indices
+  if (n_seq == 0) return hip_rc(hipMemsetAsync(counts, 0, 2 * sizeof(int64_t), (hipStream_t)stream));
+  if (!ws || ws_bytes < xnrs_row_lists_workspace_bytes(n_seq)) return XNRS_EWORKSPACE;
+  return hip_rc(launch_build_row_lists(m, ids, n_seq, L, live_rows, ids ? live_src_rows : nullptr, kv_rows,
+                                       ids ? kv_src_rows : nullptr, counts, static_cast<int32_t*>(ws), (hipStream_t)stream));
+}
 
 const char* xnrs_error_string(int32_t code) {
   switch (code) {
@@ -1153,8 +1210,8 @@ namespace {
 
 struct BwdPlan {
   size_t off_dh, off_dp, off_dseq, off_dpre, off_de, off_docat, off_dqkv, off_delta, off_slabs, off_colsum, off_wt;
-  // folded out-projection (training): g = dp.Wo, c = dp.bo, dW', db', the stacked operands of dWo / dbo
-  size_t off_g, off_c, off_dwf, off_dbf, off_sta, off_stb, off_stw;
+  // folded out-projection (training): g = dp.Wo, c = dp.bo, dW', db'
+  size_t off_g, off_c, off_dwf, off_dbf;
   size_t total;
 };
 
@@ -1183,14 +1240,11 @@ BwdPlan make_bwd_plan(int64_t n_seq, int L, int D, int A, int E, int n_heads, bo
   p.off_c = foldable ? take((size_t)n_seq * 4) : 0;
   p.off_dwf = foldable ? take((size_t)A * D * 4) : 0;
   p.off_dbf = foldable ? take((size_t)A * 4) : 0;
-  p.off_sta = foldable ? take(((size_t)n_seq + A) * D * 4) : 0;
-  p.off_stb = foldable ? take(((size_t)n_seq + A) * D * 4) : 0;
-  p.off_stw = foldable ? take(((size_t)n_seq + A) * 4) : 0;
   // split-K slabs: the largest dW this pipeline produces
   size_t slabs = 0;
-  if (att) slabs = max_sz(slabs, gemm_splitk_workspace_bytes(D, D, rows));
+  if (att) slabs = max_sz(slabs, gemm_splitk_workspace_bytes(2 * (int64_t)D, D, rows));  // (dWk | dWv as one product)
   if (additive) slabs = max_sz(slabs, gemm_splitk_workspace_bytes(A, D, rows));
-  if (foldable) slabs = max_sz(slabs, gemm_splitk_workspace_bytes(D, D, (int64_t)n_seq + A));  // stacked dWo product
+  if (foldable) slabs = max_sz(slabs, gemm_splitk_workspace_bytes(D, D, (int64_t)n_seq));  // dWo = dp^T po (+ W1^T dW')
   if (pooled && head) {
     slabs = max_sz(slabs, gemm_splitk_workspace_bytes(E, D, n_seq));
     slabs = max_sz(slabs, gemm_splitk_workspace_bytes(E, E, n_seq));
@@ -1216,7 +1270,10 @@ BwdPlan make_bwd_plan(int64_t n_seq, int L, int D, int A, int E, int n_heads, bo
 // kernel adds up the dY chunks it stages; a separate column-sum pass re-read every dY from HBM: 8.6 % of the train step)
 hipError_t gemm_dw(const float* dY, int64_t lddy, const float* X, const int32_t* x_ids, int x_S, int64_t ldx, float* dW,
                    int64_t M, int N, int K, float* slabs, hipStream_t stream, const int32_t* live_dy = nullptr,
-                   const int32_t* live_x = nullptr, int64_t n_live = 0, float* db = nullptr, float* csum = nullptr) {
+                   const int32_t* live_x = nullptr, int64_t n_live = 0, float* db = nullptr, float* csum = nullptr,
+                   const int64_t* k_dev = nullptr, int accumulate = 0, float* dW2 = nullptr, float* db2 = nullptr, int n1 = 0) {
+  // dW2 / db2 / n1 (optional): the product covers TWO parameters -- output rows [0, n1) are dW / db, rows [n1, N) are dW2 /
+  // db2 (dY columns side by side, the same contraction rows): one launch instead of two (needs split-K; else two calls)
   const int64_t M_all = M;
   GemmArgs g{};
   g.A = dY;
@@ -1247,19 +1304,36 @@ hipError_t gemm_dw(const float* dY, int64_t lddy, const float* X, const int32_t*
   g.ldc = K;
   g.M = N;
   g.K = M;
+  g.k_dev = live_dy ? k_dev : nullptr;  // the list's length on the device (M is then its capacity)
+  g.accumulate = accumulate;
   const int ns = gemm_pick_splits(N, K, M, knobs().gemm_dw && gemm_dw_eligible(g));
   if (ns > 1) {
     g.slabs = slabs;
     g.nsplit = ns;
   }
   const bool fuse_db = db && csum && (lddy % 4 == 0) && (N % 4 == 0);  // the k-major vector path stages dY as 16-byte chunks
-  if (fuse_db) g.colsum = csum;
-  int nsplit_used = 1;
-  ProfScope ps(7, 2.0 * (double)M * N * K, stream);  // M = the rows actually contracted (the live ones)
-  hipError_t e = launch_gemm_f32(g, stream, &nsplit_used);
+  if (dW2) {
+    const int64_t per = ((M + ns - 1) / ns + 31) / 32 * 32;  // (the launcher's slice rule: is there really more than one?)
+    if (ns <= 1 || (M + per - 1) / per <= 1 || (db && !fuse_db) || (!db != !db2)) {  // no split-K reduction to route the rows: two products
+      hipError_t e1 = gemm_dw(dY, lddy, X, x_ids, x_S, ldx, dW, M_all, n1, K, slabs, stream, live_dy, live_x, n_live, db, csum, k_dev,
+                              accumulate);
+      if (e1 != hipSuccess) return e1;
+      return gemm_dw(dY + n1, lddy, X, x_ids, x_S, ldx, dW2, M_all, N - n1, K, slabs, stream, live_dy, live_x, n_live, db2, csum,
+                     k_dev, accumulate);
+    }
+    g.C2 = dW2;
+    g.c2_row0 = n1;
+    g.colsum_out2 = db2;
+  }
+  if (fuse_db) {  // partials per K slice; the split-K reduction launch adds them up into db (GemmArgs::colsum_out)
+    g.colsum = csum;
+    g.colsum_out = db;
+  }
+  // M = the rows actually contracted (the live ones)
+  ProfScope ps(7, 2.0 * (double)prof_count(7, g.k_dev, 0, M, stream) * N * K, stream);
+  hipError_t e = launch_gemm_f32(g, stream);
   if (e != hipSuccess) return e;
-  if (fuse_db) return launch_colsum_final(csum, nsplit_used, N, db, stream);
-  if (db) return launch_colsum(dY, lddy, nullptr, M_all, N, db, csum, stream);  // all rows (the non-live ones are zero)
+  if (db && !fuse_db) return launch_colsum(dY, lddy, nullptr, M_all, N, db, csum, stream);  // all rows (the non-live ones are zero)
   return hipSuccess;
 }
 
@@ -1269,7 +1343,8 @@ hipError_t gemm_dw(const float* dY, int64_t lddy, const float* X, const int32_t*
 // CU: ~133 TF -- instead of the k-major variant (87 TF on the 80 000-row dX GEMMs of the NRMS train step).
 hipError_t gemm_dx(const float* dY, int64_t lddy, const float* W, float* dX, int64_t lddx, int64_t M, int N, int K,
                    const float* aux, int64_t ldaux, int aux_mode, int accumulate, hipStream_t stream,
-                   float* wt_scratch = nullptr, const int32_t* live = nullptr, int64_t n_live = 0) {
+                   float* wt_scratch = nullptr, const int32_t* live = nullptr, int64_t n_live = 0,
+                   const int64_t* m_dev = nullptr) {
   GemmArgs g{};
   g.A = dY;
   g.lda = lddy;
@@ -1279,6 +1354,8 @@ hipError_t gemm_dx(const float* dY, int64_t lddy, const float* W, float* dX, int
     g.gather_S = 1;
     g.c_scatter = 1;
     M = n_live;
+    g.m_dev = m_dev;  // the list's length on the device (n_live is then its capacity)
+    g.m_fill_hint = 0.4f;
   }
   g.nseg = 1;
   g.Nseg = K;
@@ -1290,8 +1367,9 @@ hipError_t gemm_dx(const float* dY, int64_t lddy, const float* W, float* dX, int
   g.ldaux = ldaux;
   g.aux_mode = aux_mode;
   g.accumulate = accumulate;
-  ProfScope ps(8, 2.0 * (double)M * N * K, stream);
-  if (wt_scratch && M >= 4096) {
+  ProfScope ps(8, 2.0 * (double)prof_count(8, g.m_dev, 0, M, stream) * N * K, stream);
+  if (g.m_dev && !wt_scratch) return hipErrorInvalidValue;  // device row counts: forward-layout kernel only
+  if (wt_scratch && (M >= 4096 || g.m_dev)) {
     hipError_t e = launch_transpose(W, wt_scratch, N, K, stream);  // Wt[K][N]
     if (e != hipSuccess) return e;
     g.W[0] = wt_scratch;
@@ -1355,8 +1433,7 @@ int32_t xnrs_seq_encoder_fwd_train_rows(const float* x, const float* m, const in
   // a gathered table needs the table rows of the listed tokens
   if (ids && ((r->live_rows && !r->live_src_rows) || (r->kv_rows && !r->kv_src_rows))) return XNRS_EINVAL;
   return seq_encode(x, m, ids, n_seq, L, D, att, pooled, pool_kind, pool, pooled ? head : nullptr, y, a_out, hm, 0, saved,
-                    saved_bytes, (hipStream_t)stream, true, r->live_rows, r->live_src_rows, r->n_live, r->kv_rows,
-                    r->kv_src_rows, r->n_kv, r->qkv_shared);
+                    saved_bytes, (hipStream_t)stream, true, r);
 }
 
 size_t xnrs_seq_encoder_bwd_workspace_bytes(int64_t n_seq, int32_t L, int32_t D, int32_t A, int32_t E, int32_t n_heads,
@@ -1398,8 +1475,12 @@ int32_t xnrs_seq_encoder_bwd_rows(const float* x, const float* m, const int32_t*
   if (!rl) rl = &none;
   const int32_t* live_rows = rl->live_rows;
   const int32_t* live_src_rows = rl->live_src_rows;
-  const int64_t n_live = rl->n_live;
+  // counts on the device (xnrs_row_lists::counts_dev): n_live / n_kv are then the lists' capacities (every row)
+  const int64_t* cnt = rl->counts_dev;
+  const int64_t n_live = cnt ? n_seq * L : rl->n_live, n_kv = cnt ? n_seq * L : rl->n_kv;
   if (rl->kv_rows && !live_rows) return XNRS_EINVAL;
+  if (rl->dqkv_mode != XNRS_DQKV_OWN && (rl->dqkv_mode < 0 || rl->dqkv_mode > XNRS_DQKV_MERGE || !att || !rl->dqkv_image || dx))
+    return XNRS_EINVAL;
   if (ids && rl->kv_rows && !rl->kv_src_rows) return XNRS_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   if (n_seq == 0) return XNRS_OK;
@@ -1434,7 +1515,8 @@ int32_t xnrs_seq_encoder_bwd_rows(const float* x, const float* m, const int32_t*
   float* dpre = reinterpret_cast<float*>(w + bp.off_dpre);
   float* de = reinterpret_cast<float*>(w + bp.off_de);
   float* docat = reinterpret_cast<float*>(w + bp.off_docat);
-  float* dqkv = reinterpret_cast<float*>(w + bp.off_dqkv);
+  // (dqkv_mode: the caller's image shared by the two backward calls over one Q|K|V image, xnrs_row_lists)
+  float* dqkv = rl->dqkv_mode != XNRS_DQKV_OWN ? rl->dqkv_image : reinterpret_cast<float*>(w + bp.off_dqkv);
   float* delta = reinterpret_cast<float*>(w + bp.off_delta);
   float* slabs = reinterpret_cast<float*>(w + bp.off_slabs);
   float* csum = reinterpret_cast<float*>(w + bp.off_colsum);
@@ -1443,13 +1525,16 @@ int32_t xnrs_seq_encoder_bwd_rows(const float* x, const float* m, const int32_t*
   // Live rows (optional): the unmasked token rows.  A masked row has pooling weight 0, so every gradient that passes
   // through it is exactly zero (dy_i = a_i dp = 0, dpre_i = 0, dO_i = 0, dS_i = 0): the row-parallel GEMMs of the
   // attention tower run over the live rows only, in place.  K and V gradients stay dense (padded rows are keys).
-  const bool live = live_rows && pooled && additive && m && n_live >= 0 && n_live < rows;
+  const bool live = live_rows && pooled && additive && m && (cnt || (n_live >= 0 && n_live < rows));
+  if (cnt && live && !device_counts_ok(x, D, A, att, pool)) return XNRS_EUNSUPPORTED;
+  const int64_t* cnt_live = (cnt && live) ? cnt : nullptr;
   const int32_t* lv = live ? live_rows : nullptr;
   const int32_t* lvx = live ? (live_src_rows ? live_src_rows : live_rows) : nullptr;
   if (live_rows && ids && !live_src_rows) return XNRS_EINVAL;  // a gathered table needs the table rows of the live tokens
   // K / V gradients over the token rows of the non-empty news (the forward's kv list): an all-masked news has no live query,
   // so its dK and dV rows are exactly zero
-  const bool kvl = live && rl->kv_rows && rl->n_kv >= 0 && rl->n_kv < rows;
+  const bool kvl = live && rl->kv_rows && (cnt || (n_kv >= 0 && n_kv < rows));
+  const int64_t* cnt_kv = (cnt && kvl) ? cnt + 1 : nullptr;
   const int32_t* kvr = kvl ? rl->kv_rows : nullptr;
   const int32_t* kvx = kvl ? (rl->kv_src_rows ? rl->kv_src_rows : rl->kv_rows) : nullptr;
   const bool fold = att && pooled && additive && fold_wanted(knobs().fold_train);  // = the forward's decision
@@ -1487,9 +1572,6 @@ int32_t xnrs_seq_encoder_bwd_rows(const float* x, const float* m, const int32_t*
       float* cvec = reinterpret_cast<float*>(w + bp.off_c);
       float* dwf = reinterpret_cast<float*>(w + bp.off_dwf);
       float* dbf = reinterpret_cast<float*>(w + bp.off_dbf);
-      float* sta = reinterpret_cast<float*>(w + bp.off_sta);
-      float* stb = reinterpret_cast<float*>(w + bp.off_stb);
-      float* stw = reinterpret_cast<float*>(w + bp.off_stw);
       XNRS_TRY(gemm_dx(dpool, D, att->wo, gvec, D, n_seq, D, D, nullptr, 0, 0, 0, stream, wt));
       if (att->bo)
         XNRS_TRY(launch_gemm_f32(gemm1(dpool, nullptr, 0, D, att->bo, nullptr, cvec, 1, n_seq, 1, D, XNRS_ACT_NONE), stream));
@@ -1512,29 +1594,23 @@ int32_t xnrs_seq_encoder_bwd_rows(const float* x, const float* m, const int32_t*
       XNRS_TRY(launch_additive_pool_bwd(pa, stream));
       if (g_pool && g_pool->w2) XNRS_TRY(launch_colsum(t, A, de, rows, A, g_pool->w2, csum, stream));
       if (g_pool && g_pool->b2) XNRS_TRY(launch_colsum(de, 1, nullptr, rows, 1, g_pool->b2, csum, stream));
-      XNRS_TRY(gemm_dw(dpre, A, o, nullptr, 0, D, dwf, rows, A, D, slabs, stream, lv, lv, n_live, dbf, csum));
-      XNRS_TRY(gemm_dx(dpre, A, wf, docat, D, rows, A, D, nullptr, 0, 0, /*accumulate*/ 1, stream, wt, lv, n_live));
+      XNRS_TRY(gemm_dw(dpre, A, o, nullptr, 0, D, dwf, rows, A, D, slabs, stream, lv, lv, n_live, dbf, csum, cnt_live));
+      XNRS_TRY(gemm_dx(dpre, A, wf, docat, D, rows, A, D, nullptr, 0, 0, /*accumulate*/ 1, stream, wt, lv, n_live, cnt_live));
       if (g_pool && g_pool->w1) {
         XNRS_TRY(launch_gemm_f32(gemm1(dwf, nullptr, 0, D, att->wo, nullptr, g_pool->w1, D, A, D, D, XNRS_ACT_NONE), stream));
         if (att->bo) XNRS_TRY(launch_add_rowscaled_bias(g_pool->w1, D, dbf, att->bo, A, D, stream));
       }
       if (g_pool && g_pool->b1)
         XNRS_TRY(hipMemcpyAsync(g_pool->b1, dbf, (size_t)A * sizeof(float), hipMemcpyDeviceToDevice, stream));
-      if (g_att && (g_att->wo || g_att->bo)) {
-        const size_t nd = (size_t)n_seq * D * sizeof(float), ad = (size_t)A * D * sizeof(float);
-        XNRS_TRY(hipMemcpyAsync(sta, dpool, nd, hipMemcpyDeviceToDevice, stream));
-        XNRS_TRY(hipMemcpyAsync(sta + (size_t)n_seq * D, pool->w1, ad, hipMemcpyDeviceToDevice, stream));
-        if (g_att->wo) {
-          XNRS_TRY(hipMemcpyAsync(stb, pob, nd, hipMemcpyDeviceToDevice, stream));
-          XNRS_TRY(hipMemcpyAsync(stb + (size_t)n_seq * D, dwf, ad, hipMemcpyDeviceToDevice, stream));
-          XNRS_TRY(gemm_dw(sta, D, stb, nullptr, 0, D, g_att->wo, n_seq + A, D, D, slabs, stream));
-        }
-        if (g_att->bo) {
-          XNRS_TRY(hipMemcpyAsync(stw, asum, (size_t)n_seq * sizeof(float), hipMemcpyDeviceToDevice, stream));
-          XNRS_TRY(hipMemcpyAsync(stw + n_seq, dbf, (size_t)A * sizeof(float), hipMemcpyDeviceToDevice, stream));
-          XNRS_TRY(launch_colsum(sta, D, stw, n_seq + A, D, g_att->bo, csum, stream));
-        }
+      // dWo = dp^T po + W1^T dW' as two products (the second accumulates), dbo = sum_n s_n dp_n + sum_a db'_a W1[a,:] as ONE
+      // column sum over the two row blocks (round 3 staged [dp; W1] and [po; dW'] with six device copies per call)
+      if (g_att && g_att->wo) {
+        XNRS_TRY(gemm_dw(dpool, D, pob, nullptr, 0, D, g_att->wo, n_seq, D, D, slabs, stream));
+        XNRS_TRY(gemm_dw(pool->w1, D, dwf, nullptr, 0, D, g_att->wo, A, D, D, slabs, stream, nullptr, nullptr, 0, nullptr, nullptr,
+                         nullptr, /*accumulate*/ 1));
       }
+      if (g_att && g_att->bo) XNRS_TRY(launch_colsum2(dpool, D, asum, n_seq, pool->w1, D, dbf, A, D, g_att->bo, csum, stream));
+
     } else {
     const float* seq = att ? yatt : x;
     const int32_t* seq_ids = att ? nullptr : ids;
@@ -1561,12 +1637,12 @@ int32_t xnrs_seq_encoder_bwd_rows(const float* x, const float* m, const int32_t*
       if (g_pool && g_pool->w2) XNRS_TRY(launch_colsum(t, A, de, rows, A, g_pool->w2, csum, stream));
       if (g_pool && g_pool->b2) XNRS_TRY(launch_colsum(de, 1, nullptr, rows, 1, g_pool->b2, csum, stream));
       if (g_pool && g_pool->w1 && live)  // rows of dpre through lv; rows of seq through lv (yatt) or lvx (x / table rows)
-        XNRS_TRY(gemm_dw(dpre, A, seq, nullptr, 0, D, g_pool->w1, rows, A, D, slabs, stream, lv, att ? lv : lvx, n_live, g_pool->b1, csum));
+        XNRS_TRY(gemm_dw(dpre, A, seq, nullptr, 0, D, g_pool->w1, rows, A, D, slabs, stream, lv, att ? lv : lvx, n_live, g_pool->b1, csum, cnt_live));
       else if (g_pool && g_pool->w1)
         XNRS_TRY(gemm_dw(dpre, A, seq, seq_ids, L, D, g_pool->w1, rows, A, D, slabs, stream, nullptr, nullptr, 0, g_pool->b1, csum));
       else if (g_pool && g_pool->b1) XNRS_TRY(launch_colsum(dpre, A, nullptr, rows, A, g_pool->b1, csum, stream));
       if (need_dseq)
-        XNRS_TRY(gemm_dx(dpre, A, pool->w1, dseq_dst, D, rows, A, D, nullptr, 0, 0, /*accumulate*/ 1, stream, wt, lv, n_live));
+        XNRS_TRY(gemm_dx(dpre, A, pool->w1, dseq_dst, D, rows, A, D, nullptr, 0, 0, /*accumulate*/ 1, stream, wt, lv, n_live, cnt_live));
     } else if (need_dseq) {
       XNRS_TRY(launch_mean_pool_bwd(dpool, m, ids, dseq_dst, D, n_seq, L, D, stream));
     }
@@ -1580,10 +1656,10 @@ int32_t xnrs_seq_encoder_bwd_rows(const float* x, const float* m, const int32_t*
   // ---- out projection: yatt = O Wo^T + bo   (folded: docat and the Wo / bo gradients are complete already)
   if (!fold) {
     if (g_att && g_att->wo)
-      XNRS_TRY(gemm_dw(dseq_src, D, o, nullptr, 0, D, g_att->wo, rows, D, D, slabs, stream, lv, lv, n_live, g_att->bo, csum));
+      XNRS_TRY(gemm_dw(dseq_src, D, o, nullptr, 0, D, g_att->wo, rows, D, D, slabs, stream, lv, lv, n_live, g_att->bo, csum, cnt_live));
     else if (g_att && g_att->bo) XNRS_TRY(launch_colsum(dseq_src, D, nullptr, rows, D, g_att->bo, csum, stream));
     if (live) XNRS_TRY(hipMemsetAsync(docat, 0, (size_t)rows * D * sizeof(float), stream));  // dO of a masked row is zero
-    XNRS_TRY(gemm_dx(dseq_src, D, att->wo, docat, D, rows, D, D, nullptr, 0, 0, 0, stream, wt, lv, n_live));
+    XNRS_TRY(gemm_dx(dseq_src, D, att->wo, docat, D, rows, D, D, nullptr, 0, 0, 0, stream, wt, lv, n_live, cnt_live));
   }
   // ---- attention core
   MhaBwdArgs mb{};
@@ -1610,26 +1686,45 @@ int32_t xnrs_seq_encoder_bwd_rows(const float* x, const float* m, const int32_t*
   mb.scaled = att->scaled;
   mb.dropout_p = att->dropout_p;
   mb.seed = att->seed;
+  mb.seed_dev = att->seed_dev;
   mb.masked_do_is_zero = (pooled && m) ? 1 : 0;  // both poolers give masked rows a zero gradient
   // an all-masked news has dQ = dK = dV = 0: written without reading (1), or -- when every consumer goes through the row
   // lists and no input gradient is asked for -- not even written (2)
-  const bool lists_only = kvl && !dx && g_att && g_att->wq && g_att->wk && g_att->wv;  // (a bias-only gradient sums dense rows)
+  // (a deferring call: the merging call that consumes its image reads it through the same lists -- the caller's contract)
+  const bool lists_only = kvl && !dx && (rl->dqkv_mode == XNRS_DQKV_DEFER || (g_att && g_att->wq && g_att->wk && g_att->wv));  // (a bias-only gradient sums dense rows)
   mb.dead_seq_mode = live ? (lists_only ? 2 : 1) : 0;
+  mb.accumulate = rl->dqkv_mode == XNRS_DQKV_MERGE ? 1 : 0;
   {
     ProfScope ps(9, 10.0 * rows * (double)L * D, stream);  // S, dP, dV, dK, dQ: five S x S x d_k products per head
     XNRS_TRY(launch_mha_bwd(mb, stream));
   }
+  if (rl->dqkv_mode == XNRS_DQKV_DEFER) return XNRS_OK;  // the merging call computes the projection gradients from the sum
   // ---- Q/K/V projections
   float* gw[3] = {g_att ? g_att->wq : nullptr, g_att ? g_att->wk : nullptr, g_att ? g_att->wv : nullptr};
   float* gb[3] = {g_att ? g_att->bq : nullptr, g_att ? g_att->bk : nullptr, g_att ? g_att->bv : nullptr};
   const float* wqkv[3] = {att->wq, att->wk, att->wv};
+  // dWk | dWv as ONE product when both are wanted and contract over the same rows: the K and V columns of the image lie side
+  // by side (A = the 2D columns from D on), X is staged once per tile for both, the split-K reduction routes the two halves
+  // (and their bias sums) to the two parameters -- half the launches and K loops twice as long per workgroup
+  bool kv_merged = false;
+  if (gw[1] && gw[2] && !dx && (!gb[1] == !gb[2])) {
+    const float* dkv = dqkv + D;
+    if (kvl)
+      XNRS_TRY(gemm_dw(dkv, 3 * (int64_t)D, x, nullptr, 0, D, gw[1], rows, 2 * D, D, slabs, stream, kvr, kvx, n_kv, gb[1], csum, cnt_kv,
+                       0, gw[2], gb[2], D));
+    else
+      XNRS_TRY(gemm_dw(dkv, 3 * (int64_t)D, x, ids, L, D, gw[1], rows, 2 * D, D, slabs, stream, nullptr, nullptr, 0, gb[1], csum,
+                       nullptr, 0, gw[2], gb[2], D));
+    kv_merged = true;
+  }
   for (int s3 = 0; s3 < 3; ++s3) {
     const float* dpart = dqkv + (int64_t)s3 * D;
+    if (kv_merged && s3 > 0) continue;
     if (gw[s3]) {
       if (s3 == 0 && live)  // dQ is zero on masked rows; dK / dV are not (padded tokens are keys) ...
-        XNRS_TRY(gemm_dw(dpart, 3 * (int64_t)D, x, nullptr, 0, D, gw[s3], rows, D, D, slabs, stream, lv, lvx, n_live, gb[s3], csum));
+        XNRS_TRY(gemm_dw(dpart, 3 * (int64_t)D, x, nullptr, 0, D, gw[s3], rows, D, D, slabs, stream, lv, lvx, n_live, gb[s3], csum, cnt_live));
       else if (s3 > 0 && kvl)  // ... except on the rows of an all-masked news
-        XNRS_TRY(gemm_dw(dpart, 3 * (int64_t)D, x, nullptr, 0, D, gw[s3], rows, D, D, slabs, stream, kvr, kvx, rl->n_kv, gb[s3], csum));
+        XNRS_TRY(gemm_dw(dpart, 3 * (int64_t)D, x, nullptr, 0, D, gw[s3], rows, D, D, slabs, stream, kvr, kvx, n_kv, gb[s3], csum, cnt_kv));
       else
         XNRS_TRY(gemm_dw(dpart, 3 * (int64_t)D, x, ids, L, D, gw[s3], rows, D, D, slabs, stream, nullptr, nullptr, 0, gb[s3], csum));
     } else if (gb[s3]) {

@@ -26,6 +26,7 @@ __device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t a, uint64_t b)
 
 // one thread per output id
 __global__ __launch_bounds__(256) void assemble_train_kernel(BatchArgs a) {
+  XNRS_KERNEL_ENTRY();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int W = a.l_hist + 1 + a.n_neg;
   if (i >= a.B * W) return;
@@ -60,6 +61,7 @@ hipError_t launch_assemble_train(const BatchArgs& a, hipStream_t stream) {
 
 // one wave per impression: history ids + candidate CSR fill (offsets computed by the caller)
 __global__ __launch_bounds__(256) void assemble_eval_kernel(BatchArgs a) {
+  XNRS_KERNEL_ENTRY();
   const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= a.B) return;
   const int lane = threadIdx.x & 63;
@@ -88,6 +90,7 @@ hipError_t launch_assemble_eval(const BatchArgs& a, hipStream_t stream) {
 // r[e] = <vecs[cand_rows[e], :], u[cand_sess[e], :]> : one wave per candidate entry
 __global__ __launch_bounds__(256) void score_csr_kernel(const float* vecs, const int32_t* rows, const int32_t* sess, const float* u,
                                                          float* r, int64_t n, int E, int relu) {
+  XNRS_KERNEL_ENTRY();
   const int64_t e = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (e >= n) return;
   const int lane = threadIdx.x & 63;
@@ -113,6 +116,7 @@ hipError_t launch_score_csr(const float* vecs, const int32_t* rows, const int32_
 // tie order is unspecified).  out[b, :] = {ndcg@5, ndcg@10, rr, ctr@1, ctr@10, auc, acc, rec, prec}.
 __global__ __launch_bounds__(256) void rank_metrics_kernel(const float* score, const float* target, const int64_t* off, float* out,
                                                             int64_t B) {
+  XNRS_KERNEL_ENTRY();
   const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
   const int lane = threadIdx.x & 63;
@@ -198,6 +202,7 @@ hipError_t launch_rank_metrics(const float* score, const float* target, const in
 template <bool VEC>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids,
                                                            float* __restrict__ out, int64_t row_floats, int pieces) {
+  XNRS_KERNEL_ENTRY();
   const int64_t row = blockIdx.x / pieces;
   const int piece = (int)(blockIdx.x - row * pieces);
   const int64_t src = (int64_t)ids[row] * row_floats, dst = row * row_floats;
@@ -253,6 +258,7 @@ __global__ __launch_bounds__(1024) void compact_rows_kernel(const float* __restr
                                                              int64_t n_news, int64_t chunk, int S, int64_t* __restrict__ row_off_all,
                                                              int32_t* __restrict__ live_all, int32_t* __restrict__ kvs_all,
                                                              int32_t* __restrict__ kvb_all, int64_t* __restrict__ counts_all) {
+  XNRS_KERNEL_ENTRY();
   __shared__ int s_cnt[1024];
   __shared__ int s_ex[2][1024];
   __shared__ int s_wsum[2][16];
@@ -353,6 +359,7 @@ __global__ __launch_bounds__(1024) void compact_rows64_kernel(const float* __res
                                                                int64_t n_news, int64_t chunk, int S, int64_t* __restrict__ row_off_all,
                                                                int32_t* __restrict__ live_all, int32_t* __restrict__ kvs_all,
                                                                int32_t* __restrict__ kvb_all, int64_t* __restrict__ counts_all) {
+  XNRS_KERNEL_ENTRY();
   __shared__ unsigned long long s_bits[1024];
   __shared__ int64_t s_row[1024];
   __shared__ int s_ex[2][1024];
@@ -440,8 +447,127 @@ __global__ __launch_bounds__(1024) void compact_rows64_kernel(const float* __res
   }
 }
 
+// ---- the grad step's row lists on the device (xnrs_build_row_lists): the unmasked token rows ("live") and all token rows of
+// the non-empty sequences ("kv"), each in the batch's own row space [n_seq*L] and -- with a gathered table -- in the table's,
+// plus both counts as device scalars the GEMMs read (GemmArgs::m_dev / k_dev).  Replaces the torch bookkeeping of
+// xnrs_amd/autograd.py (a nonzero + ONE host read of the counts per encoder call).  Two short launches, both chip-wide:
+//   counts: a wave per sequence -> cnt[seq] = live tokens (ballot popcounts)
+//   lists : a workgroup per 64 sequences: its base offsets = sums over cnt[0 .. first) (coalesced, a few KB), a wave scan
+//           over its own 64 counts, then a wave per sequence places its tokens by ballot.  Order = row order, exactly the
+//           lists torch.nonzero gave.
+__global__ __launch_bounds__(256) void row_counts_kernel(const float* __restrict__ mask, const int32_t* __restrict__ ids,
+                                                          int64_t n_seq, int L, int32_t* __restrict__ cnt) {
+  XNRS_KERNEL_ENTRY();
+  const int lane = threadIdx.x & 63;
+  const int64_t seq = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (seq >= n_seq) return;
+  const float* mp = mask + (ids ? (int64_t)ids[seq] : seq) * L;
+  int c = 0;
+  for (int s0 = 0; s0 < L; s0 += 64) c += __popcll(__ballot(s0 + lane < L && mp[s0 + lane] != 0.f));
+  if (lane == 0) cnt[seq] = c;
+}
+
+constexpr int RL_SEQ = 64;  // sequences per workgroup of row_lists_kernel
+__global__ __launch_bounds__(1024) void row_lists_kernel(const float* __restrict__ mask, const int32_t* __restrict__ ids,
+                                                          int64_t n_seq, int L, const int32_t* __restrict__ cnt,
+                                                          int32_t* __restrict__ live, int32_t* __restrict__ live_src,
+                                                          int32_t* __restrict__ kv, int32_t* __restrict__ kv_src,
+                                                          int64_t* __restrict__ counts) {
+  XNRS_KERNEL_ENTRY();
+  __shared__ int s_red[2][16];
+  __shared__ int s_base[2];
+  __shared__ int s_ex[2][RL_SEQ];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t first = (int64_t)blockIdx.x * RL_SEQ;
+  // base offsets of this workgroup: live tokens / non-empty sequences before `first`
+  int a0 = 0, a1 = 0;
+  for (int64_t i = tid; i < first; i += 1024) {
+    const int c = cnt[i];
+    a0 += c;
+    a1 += c > 0 ? 1 : 0;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    a0 += __shfl_xor(a0, off);
+    a1 += __shfl_xor(a1, off);
+  }
+  if (lane == 0) {
+    s_red[0][wave] = a0;
+    s_red[1][wave] = a1;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int b0 = 0, b1 = 0;
+    for (int w = 0; w < 16; ++w) {
+      b0 += s_red[0][w];
+      b1 += s_red[1][w];
+    }
+    s_base[0] = b0;
+    s_base[1] = b1 * L;
+  }
+  if (wave == 0) {  // exclusive scan over this workgroup's 64 sequences
+    const int64_t seq = first + lane;
+    const int c = seq < n_seq ? cnt[seq] : 0;
+    int x0 = c, x1 = c > 0 ? L : 0;
+    const int v0 = x0, v1 = x1;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int u0 = __shfl_up(x0, off), u1 = __shfl_up(x1, off);
+      if (lane >= off) {
+        x0 += u0;
+        x1 += u1;
+      }
+    }
+    s_ex[0][lane] = x0 - v0;
+    s_ex[1][lane] = x1 - v1;
+  }
+  __syncthreads();
+  const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+  for (int j = wave; j < RL_SEQ; j += 16) {
+    const int64_t seq = first + j;
+    if (seq >= n_seq) break;
+    const int64_t mrow = ids ? (int64_t)ids[seq] : seq;
+    const float* mp = mask + mrow * L;
+    const bool kept = cnt[seq] > 0;
+    int w = s_base[0] + s_ex[0][j];
+    const int e1 = s_base[1] + s_ex[1][j];
+    for (int s0 = 0; s0 < L; s0 += 64) {
+      const int sl = s0 + lane;
+      const bool on = sl < L && mp[sl] != 0.f;
+      const uint64_t b = __ballot(on);
+      if (on) {
+        const int at = w + __popcll(b & below);
+        live[at] = (int32_t)(seq * L + sl);
+        if (live_src) live_src[at] = (int32_t)(mrow * L + sl);
+      }
+      w += __popcll(b);
+      if (kept && sl < L) {
+        kv[e1 + sl] = (int32_t)(seq * L + sl);
+        if (kv_src) kv_src[e1 + sl] = (int32_t)(mrow * L + sl);
+      }
+    }
+  }
+  if (first + RL_SEQ >= n_seq && tid == 0) {  // the last workgroup knows the totals
+    const int nn = (int)(n_seq - first);
+    const int lastc = cnt[n_seq - 1];
+    counts[0] = s_base[0] + s_ex[0][nn - 1] + lastc;
+    counts[1] = s_base[1] + s_ex[1][nn - 1] + (lastc > 0 ? L : 0);
+  }
+}
+
+hipError_t launch_build_row_lists(const float* mask, const int32_t* ids, int64_t n_seq, int L, int32_t* live, int32_t* live_src,
+                                  int32_t* kv, int32_t* kv_src, int64_t* counts, int32_t* cnt_scratch, hipStream_t stream) {
+  if (n_seq <= 0 || L <= 0) return hipSuccess;
+  if (n_seq * (int64_t)L > 0x7fffffffLL) return hipErrorInvalidValue;  // int32 row indices
+  hipLaunchKernelGGL(row_counts_kernel, dim3((unsigned)((n_seq + 3) / 4)), dim3(256), 0, stream, mask, ids, n_seq, L, cnt_scratch);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(row_lists_kernel, dim3((unsigned)((n_seq + RL_SEQ - 1) / RL_SEQ)), dim3(1024), 0, stream, mask, ids, n_seq, L,
+                     cnt_scratch, live, live_src, kv, kv_src, counts);
+  return hipGetLastError();
+}
+
 // NaN over a result whose precondition turned out violated on the device (the flags of every pass, OR-ed)
 __global__ __launch_bounds__(256) void poison_kernel(float* y, int64_t n, const int64_t* flags, int n_flags, int flag_stride) {
+  XNRS_KERNEL_ENTRY();
   bool bad = false;
   for (int i = 0; i < n_flags; ++i) bad = bad || flags[(int64_t)i * flag_stride] != 0;
   if (!bad) return;

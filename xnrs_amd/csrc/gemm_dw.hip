@@ -53,6 +53,7 @@ __device__ __forceinline__ int dw_lds_off(int row, int chunk) {  // float offset
 
 template <int KG>
 __global__ __launch_bounds__(256, 3) void gemm_dw_kernel(GemmArgs a, int n_tiles, int tiles, int nsplit) {
+  XNRS_KERNEL_ENTRY();
   __shared__ __attribute__((aligned(16))) float As[2][DW_BM * DW_BK];
   __shared__ __attribute__((aligned(16))) float Bs[2][DW_BN * DW_BK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -70,9 +71,16 @@ __global__ __launch_bounds__(256, 3) void gemm_dw_kernel(GemmArgs a, int n_tiles
   const int split = w / tiles, tile = w - split * tiles;
   const int mt = tile / n_tiles, nt = tile - mt * n_tiles;
   const int m0 = mt * DW_BM, n0 = nt * DW_BN;
-  const int kbeg = (int)((int64_t)split * a.k_per_split);
-  const int kend = (int)((kbeg + a.k_per_split < a.K) ? kbeg + a.k_per_split : a.K);
-  const int Ktot = (int)a.K;
+  int Ktot = (int)a.K;
+  int kps = (int)a.k_per_split;
+  if (a.k_dev) {  // contraction length on the device (GemmArgs::k_dev): slices cut here, wave-uniform
+    const int kd = __builtin_amdgcn_readfirstlane((int)load_dev_scalar(a.k_dev));
+    Ktot = kd < Ktot ? (kd > 0 ? kd : 0) : Ktot;
+    kps = ((Ktot + nsplit - 1) / nsplit + DW_BK - 1) / DW_BK * DW_BK;
+    if (kps < DW_BK) kps = DW_BK;
+  }
+  const int kbeg = split * kps;
+  const int kend = (kbeg + kps < Ktot) ? kbeg + kps : Ktot;
 
   // ---- staging role: which operand, which 4 x 4 block of the 16 x 128 tile
   const bool isB = tid >= 128;
@@ -228,6 +236,7 @@ constexpr int DW2_BM = 256, DW2_BN = 256;
 
 template <int KG>
 __global__ __launch_bounds__(512, 2) void gemm_dw256_kernel(GemmArgs a, int n_tiles, int tiles, int nsplit) {
+  XNRS_KERNEL_ENTRY();
   __shared__ __attribute__((aligned(16))) float As[2][DW2_BM * DW_BK];
   __shared__ __attribute__((aligned(16))) float Bs[2][DW2_BN * DW_BK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -240,9 +249,16 @@ __global__ __launch_bounds__(512, 2) void gemm_dw256_kernel(GemmArgs a, int n_ti
   const int split = w / tiles, tile = w - split * tiles;
   const int mt = tile / n_tiles, nt = tile - mt * n_tiles;
   const int m0 = mt * DW2_BM, n0 = nt * DW2_BN;
-  const int kbeg = (int)((int64_t)split * a.k_per_split);
-  const int kend = (int)((kbeg + a.k_per_split < a.K) ? kbeg + a.k_per_split : a.K);
-  const int Ktot = (int)a.K;
+  int Ktot = (int)a.K;
+  int kps = (int)a.k_per_split;
+  if (a.k_dev) {  // contraction length on the device (GemmArgs::k_dev): slices cut here, wave-uniform
+    const int kd = __builtin_amdgcn_readfirstlane((int)load_dev_scalar(a.k_dev));
+    Ktot = kd < Ktot ? (kd > 0 ? kd : 0) : Ktot;
+    kps = ((Ktot + nsplit - 1) / nsplit + DW_BK - 1) / DW_BK * DW_BK;
+    if (kps < DW_BK) kps = DW_BK;
+  }
+  const int kbeg = split * kps;
+  const int kend = (kbeg + kps < Ktot) ? kbeg + kps : Ktot;
 
   const bool isB = tid >= 256;
   const int t8 = tid & 255;

@@ -86,6 +86,7 @@ constexpr unsigned BUF_OOB = 0x40000000u;
 template <int TM, int TN, bool A_COL, bool B_KN, bool VEC, int PIPE, int BK, bool BUF = false, int MINW = 2, bool GATH = false,
           int KG = 2, bool RDOT = false, bool MDEV = false>
 __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmArgs a, int m_tiles, int n_tiles_seg, int gn) {
+  XNRS_KERNEL_ENTRY();
   static_assert(!MDEV || (!A_COL && !B_KN), "device row counts: forward layout only");
   static_assert(!BUF || (!A_COL && !B_KN && VEC), "buffer loads are implemented for the forward layout");
   static_assert(!RDOT || PIPE == 5, "the fused row dots ride on the interleaved pipeline (its MFMA call is the swapped one)");
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmArgs a, i
   int64_t Mrun = a.M;
   int nwg = gridDim.x;
   if constexpr (MDEV) {
-    const int64_t md = *a.m_dev;
+    const int64_t md = load_dev_scalar(a.m_dev);
     Mrun = ((int64_t)__builtin_amdgcn_readfirstlane((int)(md >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)md);
     if (Mrun > a.M) Mrun = a.M;
     m_tiles = (int)((Mrun + BM - 1) / BM);
@@ -144,8 +145,18 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmArgs a, i
 
   // contraction indices are 32-bit in the kernel (the launcher refuses K >= 2^31): the k-tail tests and tile offsets of
   // the inner loop are then single VALU / SALU instructions instead of 64-bit compare-and-select pairs
-  const int kbeg = (int)((int64_t)blockIdx.y * a.k_per_split);
-  const int kend = (int)((kbeg + a.k_per_split < a.K) ? kbeg + a.k_per_split : a.K);
+  int64_t kps = a.k_per_split;
+  int Ktot = (int)a.K;
+  if constexpr (A_COL && B_KN) {
+    if (a.k_dev) {  // contraction length on the device (GemmArgs::k_dev): slices cut here, wave-uniform
+      const int kd = __builtin_amdgcn_readfirstlane((int)load_dev_scalar(a.k_dev));
+      Ktot = kd < Ktot ? (kd > 0 ? kd : 0) : Ktot;
+      kps = (((int64_t)Ktot + gridDim.y - 1) / gridDim.y + KALIGN - 1) / KALIGN * KALIGN;
+      if (kps < KALIGN) kps = KALIGN;
+    }
+  }
+  const int kbeg = (int)((int64_t)blockIdx.y * kps);
+  const int kend = (int)((kbeg + kps < Ktot) ? kbeg + kps : Ktot);
 
   const float* __restrict__ W = a.W[seg];
   const float* __restrict__ bias = a.bias[seg];
@@ -583,6 +594,53 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmArgs a, i
     else dots(std::false_type{});
     return;
   }
+  if constexpr (!A_COL) {
+    if (a.c_scatter) {
+      // Row subset in place: the C (and aux) rows follow A's gather list (the live-row / kv-row products of the grad step).
+      // The destination row is looked up ONCE per accumulator row -- (i, e) outermost, the TN column blocks inside -- and
+      // without the 64-bit division of the general rule when the list holds one row per id (every list of the grad
+      // step): the first version divided per ELEMENT, 64 software divisions per thread, a quarter of these launches.
+      const int32_t* __restrict__ sids = a.c_scatter_ids ? a.c_scatter_ids : a.gather_ids;
+      const bool one = a.gather_S == 1;
+      float bvj[TN];
+      int colj[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        colj[j] = n0 + wn * 32 * TN + 32 * j + ccol;
+        bvj[j] = (bias && !split && colj[j] < a.Nseg) ? bias[colj[j]] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          int64_t row = m0 + wm * 32 * TM + 32 * i + (e & 3) + 8 * (e >> 2) + crow;
+          if (row >= Mrun) continue;
+          if (one) row = sids[row];
+          else {
+            const int64_t n = row / a.gather_S;
+            row = (int64_t)sids[n] * a.gather_S + (row - n * a.gather_S);
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            if (colj[j] >= a.Nseg) continue;
+            const int64_t coff = (int64_t)seg * a.Nseg + colj[j];
+            float v = acc[i][j][e];
+            if (!split) {
+              if (a.rowscale) v = fmaf(a.rowscale[row], a.rowscale_vec[colj[j]], v);
+              v = apply_act(v + bvj[j], a.act);
+              if (a.aux_mode) {
+                const float x = a.aux[row * a.ldaux + coff];
+                v *= (a.aux_mode == 1) ? (1.f - x * x) : (x > 0.f ? 1.f : 0.f);
+              }
+              if (a.accumulate) v += Cout[row * a.ldc + coff];
+            }
+            Cout[row * a.ldc + coff] = v;
+          }
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + wn * 32 * TN + 32 * j + ccol;
@@ -595,10 +653,6 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmArgs a, i
       for (int e = 0; e < 16; ++e) {
         int64_t row = m0 + wm * 32 * TM + 32 * i + (e & 3) + 8 * (e >> 2) + crow;
         if (row < Mrun) {
-          if (!A_COL && a.c_scatter) {  // row subset in place: C (and aux) rows follow A's gather
-            const int64_t n = row / a.gather_S;
-            row = (int64_t)(a.c_scatter_ids ? a.c_scatter_ids : a.gather_ids)[n] * a.gather_S + (row - n * a.gather_S);
-          }
           float v = acc[i][j][e];
           if (!split) {
             if (a.rowscale) v = fmaf(a.rowscale[row], a.rowscale_vec[col], v);
@@ -619,6 +673,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmArgs a, i
 
 // Wt[c][r] = W[r][c]: 32x32 tiles through LDS (padded rows), both sides coalesced
 __global__ __launch_bounds__(256) void transpose_kernel(const float* W, float* Wt, int rows, int cols) {
+  XNRS_KERNEL_ENTRY();
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
@@ -638,6 +693,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* W, float* W
 // zero `width` floats (multiple of 4, 16-byte aligned) of each of `rows` rows of pitch `ld` floats: the column block of
 // one segment inside a [rows, 3D] image.  (hipMemset2DAsync took 311 us for 80 000 x 768 floats, this runs at HBM speed.)
 __global__ __launch_bounds__(256) void zero_cols_kernel(float* p, int64_t ld, int w4, int64_t n4) {
+  XNRS_KERNEL_ENTRY();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   const int64_t r = i / w4;
@@ -660,6 +716,7 @@ hipError_t launch_zero_cols(float* p, int64_t ld, int width, int64_t rows, hipSt
 // grad step's 80 000 x 2304 image (zero_cols over the whole image: 0.14 ms per encode).
 __global__ __launch_bounds__(256) void zero_dead_qkv_kernel(float* qkv, const float* __restrict__ mask,
                                                             const int32_t* __restrict__ ids, int L, int D4) {
+  XNRS_KERNEL_ENTRY();
   const int64_t seq = blockIdx.x;
   const float* mp = mask + (ids ? (int64_t)ids[seq] : seq) * L;
   int any = 0;
@@ -689,14 +746,29 @@ hipError_t launch_transpose(const float* W, float* Wt, int rows, int cols, hipSt
   return hipGetLastError();
 }
 
-// C (+)= sum_s slabs[s]  (fixed order -> bitwise reproducible)
+// C (+)= sum_s slabs[s]  (fixed order -> bitwise reproducible); elements past n: the fused bias-gradient partials
+// (GemmArgs::colsum, [nsplit][cs_n]) summed the same way into cs_out -- one launch instead of a reduce and a colsum_final
+// (C2 / n1 / cs_out2 / cs_n1: elements from n1 on -- whole rows -- go to C2, bias gradients from cs_n1 on to cs_out2:
+// GemmArgs::C2, one product for two parameters)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, int64_t slab_stride, int nsplit, float* C,
-                                                             int64_t n, int accumulate) {
+                                                             int64_t n, int accumulate, const float* cs_partial, float* cs_out,
+                                                             int cs_n, float* C2, int64_t n1, float* cs_out2, int cs_n1) {
+  XNRS_KERNEL_ENTRY();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float v = accumulate ? C[i] : 0.f;
+  if (i >= n) {
+    const int64_t c = i - n;
+    if (c < cs_n) {
+      float v = 0.f;
+      for (int s = 0; s < nsplit; ++s) v += cs_partial[(int64_t)s * cs_n + c];
+      if (cs_out2 && c >= cs_n1) cs_out2[c - cs_n1] = v;
+      else cs_out[c] = v;
+    }
+    return;
+  }
+  float* dst = (C2 && i >= n1) ? C2 + (i - n1) : C + i;
+  float v = accumulate ? *dst : 0.f;
   for (int s = 0; s < nsplit; ++s) v += slabs[(int64_t)s * slab_stride + i];
-  C[i] = v;
+  *dst = v;
 }
 
 // column tiles per group of the tile walk (see the kernel): as many as keep the group's weight panels within
@@ -812,7 +884,9 @@ static hipError_t launch_layout(const GemmArgs& a, bool vec, int nsplit, hipStre
   double best_t = 1e300;
   for (int c = 0; c < 4; ++c) {
     const int64_t bm = 64 * cand[c][0], bn = 64 * cand[c][1];
-    const int64_t wgs = ((a.M + bm - 1) / bm) * ((a.Nseg + bn - 1) / bn) * a.nseg * nsplit;
+    // (m_dev launches: the rows expected to exist, GemmArgs::m_fill_hint, not the capacity the grid is sized for)
+    const int64_t m_exp = (a.m_dev && a.m_fill_hint > 0.f && a.m_fill_hint < 1.f) ? (int64_t)(a.M * (double)a.m_fill_hint) + 1 : a.M;
+    const int64_t wgs = ((m_exp + bm - 1) / bm) * ((a.Nseg + bn - 1) / bn) * a.nseg * nsplit;
     const double slots = (A_COL || B_KN) ? 512.0 : 1024.0;
     // fractional rounds above one: workgroups are re-dispatched one by one, so 7.3 rounds of 128x128 tiles do not cost
     // 8 (whole rounds made the k-major dX GEMMs pick 128x64 tiles: 87 TF)
@@ -923,6 +997,15 @@ hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t stream, int* nsplit
   // kernel from HBM anyway: non-temporal stores keep it from evicting the operand panels (-0.5 % on the Q/K/V GEMM)
   a.nt_store = (!a.accumulate && !a.c_scatter && a.M * a.ldc * 4 >= (64ll << 20)) ? 1 : 0;
   if (a.colsum && !(a.a_col && a.b_kn)) return hipErrorInvalidValue;  // fused column sums: dW layout only
+  if (a.k_dev && !(a.a_col && a.b_kn)) return hipErrorInvalidValue;   // device contraction length: dW layout only
+  if (a.colsum_out && !a.colsum) return hipErrorInvalidValue;
+  if (a.C2 && (nsplit <= 1 || !(a.a_col && a.b_kn) || a.c2_row0 <= 0 || a.c2_row0 >= a.M)) return hipErrorInvalidValue;  // two
+                                                                                                   // destinations: split-K dW only
+  bool cs_copy = false;  // one slice: its partial IS the bias gradient (written in place when 16-byte aligned)
+  if (a.colsum && a.colsum_out && nsplit == 1) {
+    if (al16(a.colsum_out)) a.colsum = a.colsum_out;
+    else cs_copy = true;
+  }
   if (a.rowdot_out && (a.a_col || a.b_kn || a.nseg != 1 || nsplit != 1 || !a.rowdot_w || a.c_scatter || a.accumulate || a.aux_mode ||
                        (a.act != 2 && a.act != ACT_TANH_FAST)))
     return hipErrorInvalidValue;  // fused row dots: plain forward launches with a tanh epilogue only (the pooler's fc1)
@@ -948,9 +1031,13 @@ hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t stream, int* nsplit
   if (e != hipSuccess) return e;
   if (nsplit > 1) {
     const int64_t n = a.M * a.ldc;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a.slabs, a.slab_stride,
-                       nsplit, a.C, n, a.accumulate);
+    const int cs_n = (a.colsum && a.colsum_out) ? (int)a.M : 0;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + cs_n + 255) / 256)), dim3(256), 0, stream, a.slabs,
+                       a.slab_stride, nsplit, a.C, n, a.accumulate, a.colsum, a.colsum_out, cs_n, a.C2, a.c2_row0 * a.ldc,
+                       a.C2 ? a.colsum_out2 : nullptr, (int)a.c2_row0);
     e = hipGetLastError();
+  } else if (cs_copy) {
+    e = launch_colsum_final(a.colsum, 1, (int)a.M, a.colsum_out, stream);
   }
   return e;
 }

@@ -43,6 +43,30 @@ struct Knobs {
 const Knobs& knobs();
 void reload_knobs();
 
+// First statement of EVERY kernel of the library: invalidate the scalar data cache (one SALU instruction per wave; the memory
+// clobber keeps the compiler from hoisting data loads above it).  Observed on gfx950 / ROCm 7.2 with a grad step replayed
+// as a hipGraph (tools/debug_graph_step.py): wave-uniform reads that hipcc turns into SCALAR loads -- the device row count
+// of a list (GemmArgs::m_dev / k_dev), a mask row, a per-sequence scalar -- returned what an EARLIER tensor had held at the
+// same address (memory the graph's allocator pool had reused: the second replay came out NaN for about one batch in
+// three); with the invalidate and the agent-scope count load below, 64 of 64 replays equal the eager step bit for bit.
+// Ordinary launches are unaffected either way (the dispatch packet's acquire fence invalidates the cache).
+// -DXNRS_NO_CACHE_WORKAROUNDS builds the library without both, to reproduce the observation.
+#ifdef XNRS_NO_CACHE_WORKAROUNDS
+#define XNRS_KERNEL_ENTRY() ((void)0)
+#else
+#define XNRS_KERNEL_ENTRY() asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
+// A device scalar written by an EARLIER kernel on the same stream (the row counts of device-built lists), read with an
+// agent-scope load (global_load ... sc1: served by L2, past the scalar and vector L1 caches) instead of the scalar load a
+// plain `*p` compiles to.
+__device__ __forceinline__ int64_t load_dev_scalar(const int64_t* p) {
+#ifdef XNRS_NO_CACHE_WORKAROUNDS
+  return *p;
+#else
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
 // ---------------------------------------------------------------- Linear (fp32 MFMA GEMM)
 // C[M, nseg*Nseg] = act(A[M,K] . W_s[Nseg,K]^T + bias_s), s = column segment (up to 3 weights
 // side by side: the Q/K/V projections share one launch while the parameters stay separate
@@ -100,6 +124,23 @@ struct GemmArgs {
   // (<= M) the rows that exist; tiles past it return at once.  (Row lists compacted on the device: no host round trip,
   // the launch sequence does not depend on the data and can be captured in a hipGraph.)
   const int64_t* m_dev;
+  // dW layout (k-major A and B; nullable): the CONTRACTION length lives on the device -- K is the worst case the slabs and
+  // the row lists are sized for, *k_dev (<= K) the rows that exist; the kernels cut their K slices from it (an empty slice
+  // writes a zero slab).  The live-row / kv-row lists of the grad step built on the device (launch_build_row_lists): no
+  // host read of the counts, the launch sequence of the step does not depend on the data (hipGraph-capturable).
+  const int64_t* k_dev;
+  // with colsum (nullable): the final bias gradient [M]; the split-K reduction launch then also adds up the colsum
+  // partials (one launch instead of splitk_reduce + colsum_final); without split-K the kernel writes it directly
+  float* colsum_out;
+  // split-K dW launches (nullable): output rows >= c2_row0 go to C2 (row 0 of C2 = row c2_row0; same ldc) instead of C, and
+  // their bias gradients to colsum_out2 -- ONE product for two parameters whose dY columns lie side by side and whose
+  // contraction runs over the same rows (dWk | dWv: the K and V columns of the dQ|dK|dV image over the kv-row list)
+  float* C2;
+  int64_t c2_row0;
+  float* colsum_out2;
+  // forward layout with m_dev (optional): the expected fraction of the capacity M that exists (0 = unknown = all), for the
+  // tile choice only -- a launch sized for 80 000 rows of which ~25 % are live fills the chip better with smaller tiles
+  float m_fill_hint;
   // split-K (deterministic slabs + ordered reduce); set by the caller via slabs/nsplit
   float* slabs;        // nullable workspace of nsplit * M * ldc floats
   int32_t nsplit;
@@ -151,6 +192,7 @@ struct MhaCoreArgs {
   int32_t scaled;
   float dropout_p;
   uint64_t seed;
+  const uint64_t* seed_dev;  // nullable: a device word ADDED to seed (xnrs_mha_params::seed_dev: a fresh dropout draw per hipGraph replay)
   float* stats;  // nullable: per (seq, head, query) softmax row statistics {max, sum} kept for the backward
   // unpadded queries (nullable): the queries of sequence n are the COMPACT rows q_off[n] .. q_off[n+1] of q (row
   // stride ldq, head h at column h*d_k) and `out` is compact the same way; every compact query is an unmasked row
@@ -191,12 +233,18 @@ struct MhaBwdArgs {
   int32_t scaled;
   float dropout_p;
   uint64_t seed;
+  const uint64_t* seed_dev;   // as in MhaCoreArgs (the backward recomputes the forward's mask: same seed, same word)
   int32_t masked_do_is_zero;  // 1: the caller guarantees d_o == 0 on rows with mask == 0 (a masked pooler sits on top):
                               // query tiles whose 16 rows are all masked are skipped (their dQ rows are written as 0)
   // with masked_do_is_zero, fused kernel: a sequence whose query rows are ALL masked has dQ = dK = dV = 0 exactly.
   // 1: its workgroups write those zeros without reading anything; 2: they write nothing (the caller reads the gradient
   // rows of such sequences nowhere: live-row dWq, kv-row dWk / dWv, no input gradient).  0: no early exit.
   int32_t dead_seq_mode;
+  // 1: dq / dk / dv hold the gradients of ANOTHER backward over the same Q|K|V image (the reference's second history
+  // encode, training.py:406,409: same input and projection weights, another attention-dropout draw) and this launch ADDS
+  // its own -- (dQKV_1 + dQKV_2)^T . X is then ONE weight-gradient product per projection.  Rows this launch would write
+  // as zeros (masked query tiles, all-masked sequences) are left alone.
+  int32_t accumulate;
 };
 hipError_t launch_mha_bwd(const MhaBwdArgs& a, hipStream_t stream);
 
@@ -293,6 +341,11 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // (seed, element index) -> uniform [0,1).  Parity with torch's CPU Philox stream is impossible
 // (SURVEY.md section 7 "hard parts"); only the distribution matters.  Forward and backward call this with
 // the same (seed, index) so the mask is recomputed, never stored.
+// the dropout seed of a launch: the host value plus, when given, a device word (wave-uniform scalar load)
+template <class Args>
+__device__ __forceinline__ uint64_t drop_seed(const Args& a) {
+  return a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
+}
 __device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
   uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -427,6 +480,9 @@ hipError_t launch_mean_pool_bwd(const float* dy, const float* mask, const int32_
 size_t colsum_workspace_bytes(int N);
 hipError_t launch_colsum(const float* X, int64_t ldx, const float* w, int64_t M, int N, float* out, float* partial,
                          hipStream_t stream);
+// the same over two row blocks stacked: out[n] = sum_m w[m] X[m][n] + sum_m w2[m] X2[m][n]  (M2 rows of pitch ldx2)
+hipError_t launch_colsum2(const float* X, int64_t ldx, const float* w, int64_t M, const float* X2, int64_t ldx2, const float* w2,
+                          int64_t M2, int N, float* out, float* partial, hipStream_t stream);
 // out[n] = sum_s partial[s][n] in a fixed order (second stage of launch_colsum; also reduces GemmArgs::colsum)
 hipError_t launch_colsum_final(const float* partial, int nsplit, int N, float* out, hipStream_t stream);
 hipError_t launch_dot_scoring_bwd(const float* u, const float* c, const float* dr, float* du, float* dc, int64_t B, int32_t C,
@@ -469,6 +525,11 @@ hipError_t launch_poison(float* y, int64_t n, const int64_t* flags, int n_flags,
 // pass p writes row_off[p*(chunk+1) ..], the lists at [p*chunk*S ..], kv_block[p*chunk ..], counts[3*p ..]
 hipError_t launch_compact_rows(const float* mask, const int32_t* ids, int64_t n_news, int64_t chunk, int S, int64_t* row_off,
                                int32_t* live_src, int32_t* kv_src, int32_t* kv_block, int64_t* counts, hipStream_t stream);
+// the grad step's row lists built on the device (batch.hip): live[<= n_seq*L] unmasked token rows, kv[<= n_seq*L] all token
+// rows of the sequences with at least one unmasked token, both in row order; *_src (nullable, with ids): the same tokens'
+// rows in the gathered table; counts[0] = live rows, counts[1] = kv rows; cnt_scratch: int32 [n_seq]
+hipError_t launch_build_row_lists(const float* mask, const int32_t* ids, int64_t n_seq, int L, int32_t* live, int32_t* live_src,
+                                  int32_t* kv, int32_t* kv_src, int64_t* counts, int32_t* cnt_scratch, hipStream_t stream);
 hipError_t launch_assemble_train(const BatchArgs& a, hipStream_t stream);
 hipError_t launch_assemble_eval(const BatchArgs& a, hipStream_t stream);
 hipError_t launch_score_csr(const float* vecs, const int32_t* rows, const int32_t* sess, const float* u, float* r, int64_t n,

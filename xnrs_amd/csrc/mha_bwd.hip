@@ -28,6 +28,7 @@ constexpr int MAX_FT = 8;  // d_k <= 128
 // d_k products in index order.  (The first version gave every (row, head) to one thread reading 192-B pieces
 // 3 KB apart: 1 981 us for 80 000 rows; this form is bandwidth-bound.)
 __global__ __launch_bounds__(256) void mha_delta_kernel(MhaBwdArgs a, int64_t n_rows) {
+  XNRS_KERNEL_ENTRY();
   __shared__ float s_p[2048];
   const int D = a.n_heads * a.d_k;
   for (int64_t row = blockIdx.x; row < n_rows; row += gridDim.x) {
@@ -58,18 +59,22 @@ __device__ __forceinline__ f32x4 load4(const float* p, int f0, int lim, bool vec
   return v;
 }
 
-__device__ __forceinline__ void store4(float* p, int f0, int lim, bool vec, f32x4 v) {
+__device__ __forceinline__ void store4(float* p, int f0, int lim, bool vec, f32x4 v, bool acc = false) {
   if (vec) {
-    if (f0 < lim) *reinterpret_cast<f32x4*>(p + f0) = v;
+    if (f0 < lim) {
+      if (acc) v += *reinterpret_cast<const f32x4*>(p + f0);
+      *reinterpret_cast<f32x4*>(p + f0) = v;
+    }
   } else {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      if (f0 + e < lim) p[f0 + e] = v[e];
+      if (f0 + e < lim) p[f0 + e] = acc ? p[f0 + e] + v[e] : v[e];
   }
 }
 
 template <int KT, bool VEC>
 __global__ __launch_bounds__(256) void mha_dq_kernel(MhaBwdArgs a, int QT, int64_t n_units) {
+  XNRS_KERNEL_ENTRY();
   const int lane = threadIdx.x & 63;
   const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (unit >= n_units) return;
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(256) void mha_dq_kernel(MhaBwdArgs a, int QT, int64
         float dpv = dp[kt][r];
         if (a.dropout_p > 0.f) {
           const uint64_t idx = ((uint64_t)(seq * a.n_heads + hd) * S + (uint64_t)query) * S + (uint64_t)key;
-          dpv = (uniform01(a.seed, idx) < keep) ? dpv / keep : 0.f;
+          dpv = (uniform01(drop_seed(a), idx) < keep) ? dpv / keep : 0.f;
         }
         ds = p * (dpv - delta) * inv_sq;
       }
@@ -165,12 +170,13 @@ __global__ __launch_bounds__(256) void mha_dq_kernel(MhaBwdArgs a, int QT, int64
 #pragma unroll
       for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[r], s[kt][r], o, 0, 0, 0);
     }
-    if (qvalid) store4(a.dq + (row0 + query) * a.ldd + hoff, ft * 16 + 4 * g, dk, VEC, o);
+    if (qvalid) store4(a.dq + (row0 + query) * a.ldd + hoff, ft * 16 + 4 * g, dk, VEC, o, a.accumulate != 0);
   }
 }
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void mha_dkdv_kernel(MhaBwdArgs a, int KTn, int64_t n_units) {
+  XNRS_KERNEL_ENTRY();
   const int lane = threadIdx.x & 63;
   const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (unit >= n_units) return;
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(256) void mha_dkdv_kernel(MhaBwdArgs a, int KTn, in
         pdv = p;
         if (a.dropout_p > 0.f) {
           const uint64_t idx = ((uint64_t)(seq * a.n_heads + hd) * S + (uint64_t)query) * S + (uint64_t)key;
-          const bool kp = uniform01(a.seed, idx) < keep;
+          const bool kp = uniform01(drop_seed(a), idx) < keep;
           pdv = kp ? p / keep : 0.f;
           dpv = kp ? dpv / keep : 0.f;
         }
@@ -276,8 +282,8 @@ __global__ __launch_bounds__(256) void mha_dkdv_kernel(MhaBwdArgs a, int KTn, in
 #pragma unroll
     for (int t = 0; t < MAX_FT; ++t) {
       if (t < nfb) {
-        store4(dkrow, t * 16 + 4 * g, dk, VEC, dkT[t]);
-        store4(dvrow, t * 16 + 4 * g, dk, VEC, dvT[t]);
+        store4(dkrow, t * 16 + 4 * g, dk, VEC, dkT[t], a.accumulate != 0);
+        store4(dvrow, t * 16 + 4 * g, dk, VEC, dvT[t], a.accumulate != 0);
       }
     }
   }
@@ -303,6 +309,7 @@ constexpr int BWD_TLD = 20;  // row stride of the dS transpose tile
 
 template <int NFB>
 __global__ __launch_bounds__(256) void mha_bwd_fused_kernel(MhaBwdArgs a) {
+  XNRS_KERNEL_ENTRY();
   // LDS row stride (floats) of the Q / dO / partial-dQ images: 16*NFB + 4 keeps 16 consecutive rows on 16 distinct
   // 16-byte bank groups (20, 36, 52, 68 floats) and 4 rows apart on banks +16
   constexpr int BWD_LD = 16 * NFB + 4;
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(256) void mha_bwd_fused_kernel(MhaBwdArgs a) {
     if (!__syncthreads_or(tid < S && a.mask[mr + tid] != 0.f)) {
       // every query row masked: dO = 0 and dS = 0 on every row, so dQ = dK = dV = 0 -- written without reading anything
       // (mode 1), or left alone when the caller reads these rows nowhere (mode 2)
-      if (a.dead_seq_mode == 1) {
+      if (a.dead_seq_mode == 1 && !a.accumulate) {
         for (int idx = tid; idx < S * (NFB * 4); idx += 256) {
           const int row = idx / (NFB * 4), f0 = (idx - row * (NFB * 4)) * 4;
           if (f0 < dk) {
@@ -407,7 +414,7 @@ __global__ __launch_bounds__(256) void mha_bwd_fused_kernel(MhaBwdArgs a) {
       const int qq = qt * 16 + c;
       const bool lv = qq < S && a.mask[mrow + qq] != 0.f;
       if (!__any(lv)) {
-        if (wave == (qt & 3)) {
+        if (wave == (qt & 3) && !a.accumulate) {
           for (int idx = lane; idx < 16 * NCH; idx += 64) {
             const int qr = idx / NCH, f0 = (idx - qr * NCH) * 4;
             if (qt * 16 + qr < S && f0 < dk)
@@ -446,7 +453,7 @@ __global__ __launch_bounds__(256) void mha_bwd_fused_kernel(MhaBwdArgs a) {
           pdv = p;
           if (a.dropout_p > 0.f) {
             const uint64_t idx = ((uint64_t)(seq * a.n_heads + hd) * S + (uint64_t)query) * S + (uint64_t)key;
-            const bool kp = uniform01(a.seed, idx) < keep;
+            const bool kp = uniform01(drop_seed(a), idx) < keep;
             pdv = kp ? p / keep : 0.f;
             dpv = kp ? dpv / keep : 0.f;
           }
@@ -494,7 +501,9 @@ __global__ __launch_bounds__(256) void mha_bwd_fused_kernel(MhaBwdArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[e] += v[e];
           }
-          *reinterpret_cast<f32x4*>(a.dq + (row0 + query) * a.ldd + hoff + f0) = acc;
+          float* dst = a.dq + (row0 + query) * a.ldd + hoff + f0;
+          if (a.accumulate) acc += *reinterpret_cast<const f32x4*>(dst);
+          *reinterpret_cast<f32x4*>(dst) = acc;
         }
       }
     }
@@ -507,8 +516,13 @@ __global__ __launch_bounds__(256) void mha_bwd_fused_kernel(MhaBwdArgs a) {
     for (int t = 0; t < NFB; ++t) {
       const int f0 = t * 16 + 4 * g;
       if (f0 < dk) {
-        *reinterpret_cast<f32x4*>(dkrow + f0) = dkT[t];
-        *reinterpret_cast<f32x4*>(dvrow + f0) = dvT[t];
+        f32x4 kk = dkT[t], vv = dvT[t];
+        if (a.accumulate) {
+          kk += *reinterpret_cast<const f32x4*>(dkrow + f0);
+          vv += *reinterpret_cast<const f32x4*>(dvrow + f0);
+        }
+        *reinterpret_cast<f32x4*>(dkrow + f0) = kk;
+        *reinterpret_cast<f32x4*>(dvrow + f0) = vv;
       }
     }
   }

@@ -25,6 +25,7 @@ constexpr int POOLB_MAX_N = 512;
 // of 150 + 50 four-byte ones; the scalar form ran at 2.4 TB/s of its own traffic, latency-bound on the per-row loops.
 template <bool VEC>
 __global__ __launch_bounds__(256) void additive_pool_bwd_kernel(AdditivePoolBwdArgs a) {
+  XNRS_KERNEL_ENTRY();
   __shared__ float s_a[POOLB_MAX_N];
   __shared__ float s_da[POOLB_MAX_N];
   __shared__ float s_red[4];
@@ -142,6 +143,7 @@ hipError_t launch_additive_pool_bwd(const AdditivePoolBwdArgs& a, hipStream_t st
 // y = sum_i x_i m_i / (sum m + 1e-8)  ->  dx_i = dy * m_i / (sum m + 1e-8)
 __global__ __launch_bounds__(256) void mean_pool_bwd_kernel(const float* dy, const float* mask, const int32_t* mask_ids,
                                                              float* dx, int64_t lddx, int N, int D) {
+  XNRS_KERNEL_ENTRY();
   __shared__ float s_red[4];
   const int64_t seq = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -172,33 +174,37 @@ constexpr int COLSUM_ROWS = 128;
 constexpr int COLSUM_MAX_SPLITS = 4096;
 
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* X, int64_t ldx, const float* w, int64_t M, int N,
-                                                              int64_t rows_per, float* partial) {
+                                                              int64_t rows_per, float* partial, const float* X2, int64_t ldx2,
+                                                              const float* w2, int64_t M1) {
+  XNRS_KERNEL_ENTRY();
   const int n = blockIdx.x * 256 + threadIdx.x;
   const int sp = blockIdx.y;
   const int64_t r0 = sp * rows_per;
   const int64_t r1 = (r0 + rows_per < M) ? r0 + rows_per : M;
   if (n >= N) return;
+  // rows >= M1 come from the second block (launch_colsum2; M1 = M without one)
+  auto term = [&](int64_t r, float acc) {
+    const bool second = r >= M1;
+    const float x = second ? X2[(r - M1) * ldx2 + n] : X[r * ldx + n];
+    const float* ww = second ? w2 : w;
+    return ww ? fmaf(ww[second ? r - M1 : r], x, acc) : acc + x;
+  };
   // four independent chains (rows r, r+1, r+2, r+3 of every group of four), combined in a fixed order: the loads of a
   // slice are in flight together instead of one row per memory latency
   float a4[4] = {0.f, 0.f, 0.f, 0.f};
   int64_t r = r0;
   for (; r + 4 <= r1; r += 4) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float x = X[(r + e) * ldx + n];
-      a4[e] = w ? fmaf(w[r + e], x, a4[e]) : a4[e] + x;
-    }
+    for (int e = 0; e < 4; ++e) a4[e] = term(r + e, a4[e]);
   }
-  for (int e = 0; r < r1; ++r, ++e) {
-    const float x = X[r * ldx + n];
-    a4[e] = w ? fmaf(w[r], x, a4[e]) : a4[e] + x;
-  }
+  for (int e = 0; r < r1; ++r, ++e) a4[e] = term(r, a4[e]);
   const float acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
   partial[(int64_t)sp * N + n] = acc;
 }
 
 // one wave per column: lane l adds partials l, l+64, ... in order, then a fixed shuffle tree
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, int nsplit, int N, float* out) {
+  XNRS_KERNEL_ENTRY();
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
   const int lane = threadIdx.x & 63;
@@ -216,9 +222,10 @@ hipError_t launch_colsum_final(const float* partial, int nsplit, int N, float* o
 
 size_t colsum_workspace_bytes(int N) { return (size_t)COLSUM_MAX_SPLITS * (size_t)N * sizeof(float); }
 
-hipError_t launch_colsum(const float* X, int64_t ldx, const float* w, int64_t M, int N, float* out, float* partial,
-                         hipStream_t stream) {
+hipError_t launch_colsum2(const float* X, int64_t ldx, const float* w, int64_t M1, const float* X2, int64_t ldx2, const float* w2,
+                          int64_t M2, int N, float* out, float* partial, hipStream_t stream) {
   if (N <= 0) return hipSuccess;
+  const int64_t M = M1 + (X2 ? M2 : 0);
   // rows per slice: enough slices to fill the chip (~1024 workgroups with the column blocks), 8 .. COLSUM_ROWS rows each --
   // a 320-row reduction used to run as three workgroups walking 128 rows serially (31 us for 0.3 MB)
   const int64_t col_blocks = (N + 255) / 256;
@@ -230,16 +237,22 @@ hipError_t launch_colsum(const float* X, int64_t ldx, const float* w, int64_t M,
   int nsplit = (int)((M + rows_per - 1) / rows_per);
   if (nsplit < 1) nsplit = 1;
   const dim3 g1((unsigned)((N + 255) / 256), (unsigned)nsplit);
-  hipLaunchKernelGGL(colsum_partial_kernel, g1, dim3(256), 0, stream, X, ldx, w, M, N, rows_per, partial);
+  hipLaunchKernelGGL(colsum_partial_kernel, g1, dim3(256), 0, stream, X, ldx, w, M, N, rows_per, partial, X2, ldx2, w2, M1);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, partial, nsplit, N, out);
   return hipGetLastError();
 }
 
+hipError_t launch_colsum(const float* X, int64_t ldx, const float* w, int64_t M, int N, float* out, float* partial,
+                         hipStream_t stream) {
+  return launch_colsum2(X, ldx, w, M, nullptr, 0, nullptr, 0, N, out, partial, stream);
+}
+
 // r[b,c] = <c[b,c,:], u[b,:]>  ->  du[b,e] = sum_c dr[b,c] c[b,c,e] ;  dc[b,c,e] = dr[b,c] u[b,e]
 __global__ __launch_bounds__(256) void dot_scoring_bwd_kernel(const float* u, const float* c, const float* dr, float* du,
                                                                float* dc, int64_t B, int C, int E) {
+  XNRS_KERNEL_ENTRY();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= B * E) return;
   const int64_t b = i / E;
@@ -260,6 +273,7 @@ __global__ __launch_bounds__(256) void dot_scoring_bwd_kernel(const float* u, co
 constexpr int DOTN_MAX_E = 1024;
 __global__ __launch_bounds__(256) void dot_scoring_norm_bwd_kernel(const float* u, const float* c, const float* dr, float* du,
                                                                     float* dc, int C, int E) {
+  XNRS_KERNEL_ENTRY();
   __shared__ float s_du[4][DOTN_MAX_E];
   const int64_t b = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -320,6 +334,7 @@ namespace xnrs {
 // no atomics; O(n_rows * M) index compares is negligible for tables of tens to hundreds of rows.
 __global__ __launch_bounds__(64) void embedding_grad_kernel(const float* d_rows, const int32_t* ids, int64_t M, int K,
                                                              float* d_table) {
+  XNRS_KERNEL_ENTRY();
   const int r = blockIdx.x;
   for (int k0 = 0; k0 < K; k0 += 64) {
     const int k = k0 + threadIdx.x;

@@ -226,5 +226,12 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter]) -> None:
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src)
+    """Every parameter and buffer from rank `src`.  The collective writes through `t.detach()` -- the same storage AND the same
+    version counter as the parameter (a write through `t.data` would leave the counter where it was: the caches keyed on it,
+    hip.folded_fc1 and the grad step's shared projections, would keep serving the old weights on the receiving ranks) -- and
+    the caches are dropped as well."""
+    from . import hip
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.detach(), src=src)
+    hip.invalidate_fold_cache()

@@ -13,7 +13,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libxnrs_hip.so")
+#: XNRS_HIP_LIB: another build of the same sources (diagnostic builds of tools/, e.g. libxnrs_hip_stamps.so); never a fallback
+LIB_PATH = os.environ.get("XNRS_HIP_LIB") or os.path.join(_HERE, "libxnrs_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 POOL_ADDITIVE, POOL_MEAN = 0, 1
@@ -35,6 +36,7 @@ SYMBOLS = (
     "xnrs_fold_weights_workspace_bytes", "xnrs_fold_weights",
     "xnrs_text_encoder_compact_workspace_bytes", "xnrs_text_encoder_fwd_compact",
     "xnrs_seq_encoder_fwd_train_rows", "xnrs_seq_encoder_bwd_rows", "xnrs_seq_encoder_saved_qkv_offset",
+    "xnrs_build_id", "xnrs_row_lists_workspace_bytes", "xnrs_build_row_lists",
 )
 POOL_NONE = -1
 PROFILE_STAGES = ("qkv_gemm", "attention_core", "out_gemm", "fc1_tanh_gemm", "pool", "head_gemms", "news_fused",
@@ -48,7 +50,7 @@ class XnrsHipError(RuntimeError):
 
 class MhaParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo")] + [
-        ("n_heads", C.c_int32), ("scaled", C.c_int32), ("dropout_p", C.c_float), ("seed", C.c_uint64)]
+        ("n_heads", C.c_int32), ("scaled", C.c_int32), ("dropout_p", C.c_float), ("seed", C.c_uint64), ("seed_dev", C.c_void_p)]
 
 
 class AdditiveParams(C.Structure):
@@ -63,7 +65,11 @@ class HeadParams(C.Structure):
 class RowLists(C.Structure):
     """xnrs_row_lists: the unmasked token rows and the token rows of the non-empty news (include/xnrs_hip.h)."""
     _fields_ = [("live_rows", C.c_void_p), ("live_src_rows", C.c_void_p), ("n_live", C.c_int64),
-                ("kv_rows", C.c_void_p), ("kv_src_rows", C.c_void_p), ("n_kv", C.c_int64), ("qkv_shared", C.c_void_p)]
+                ("kv_rows", C.c_void_p), ("kv_src_rows", C.c_void_p), ("n_kv", C.c_int64), ("qkv_shared", C.c_void_p),
+                ("counts_dev", C.c_void_p), ("dqkv_image", C.c_void_p), ("dqkv_mode", C.c_int32)]
+
+
+DQKV_OWN, DQKV_DEFER, DQKV_MERGE = 0, 1, 2
 
 
 class MhaGrads(C.Structure):
@@ -203,10 +209,36 @@ def lib():
     l.xnrs_fold_weights_workspace_bytes.argtypes = [i32, i32]
     l.xnrs_fold_weights.restype = i32
     l.xnrs_fold_weights.argtypes = [C.POINTER(MhaParams), C.POINTER(AdditiveParams), i32, p, p, p, sz, p]
-    if l.xnrs_abi_version() != 5:
+    l.xnrs_build_id.restype = C.c_char_p
+    l.xnrs_build_id.argtypes = []
+    l.xnrs_row_lists_workspace_bytes.restype = sz
+    l.xnrs_row_lists_workspace_bytes.argtypes = [i64]
+    l.xnrs_build_row_lists.restype = i32
+    l.xnrs_build_row_lists.argtypes = [p, p, i64, i32, p, p, p, p, p, p, sz, p]
+    if l.xnrs_abi_version() != 6:
         raise XnrsHipError("libxnrs_hip.so ABI version mismatch; rebuild it")
     _lib = l
     return l
+
+
+def build_id() -> str:
+    """Hash of the sources libxnrs_hip.so was built from (include/xnrs_hip.h: xnrs_build_id)."""
+    return lib().xnrs_build_id().decode()
+
+
+def tree_build_id() -> str:
+    """The same hash over the sources in THIS tree (xnrs_amd/csrc/Makefile: ID_SRCS): equal to build_id() iff the binary
+    was built from them."""
+    import glob
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")), key=os.path.basename)
+    files += [os.path.join(csrc, "kernels.h"), os.path.join(os.path.dirname(_HERE), "include", "xnrs_hip.h")]
+    h = hashlib.sha256()
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def check(rc: int, what: str):
@@ -341,20 +373,35 @@ def additive_params(pool, att=None):
     return p, ts
 
 
-#: cache of folded fc1 weights per (attention module, pooler module): {key: (fingerprint, w1f, b1f)}.  The C ABI keeps no
-#: state between calls; this is the CALLER's cache it is designed for.  A weight update (optimizer step, load_state_dict:
-#: in-place, so the tensors' _version moves) or a move to another device (new storage) changes the fingerprint.
+#: cache of folded fc1 weights per (attention module, pooler module): {key: (weakrefs of the four source tensors, versions,
+#: w1f, b1f)}.  The C ABI keeps no state between calls; this is the CALLER's cache it is designed for.  A hit needs the four
+#: source tensors to be the very same objects (weak references, compared with `is`: a rebuilt model whose tensors land on
+#: recycled addresses can never match) at the same version counter.  An optimizer step, load_state_dict and every other
+#: in-place write through the tensor bump the counter; a write through `p.data` does NOT (torch gives `.data` its own
+#: counter): after `p.data.copy_(...)` / `dist.broadcast(p.data, ...)` call invalidate_fold_cache()
+#: (xnrs_amd.distributed.broadcast_parameters does, and writes through `p.detach()`, which shares the counter).
 FOLD_CACHE = os.environ.get("XNRS_FOLD_CACHE", "1") != "0"
 _fold_cache = {}
 
 
+def invalidate_fold_cache():
+    """Forget every cached folded fc1 pair (and the grad step's shared projections / outputs): call after writing weights in
+    a way torch's version counters do not see (`p.data.copy_`, a collective on `p.data`, a raw pointer write)."""
+    _fold_cache.clear()
+    from . import autograd
+    autograd._QKV_IMAGES.clear()
+    autograd._OUTPUTS.clear()
+
+
 def folded_fc1(att, pool):
+    import weakref
     src = (att.out.weight, att.out.bias, pool.fc1.weight, pool.fc1.bias)
-    fp = tuple((t.data_ptr(), t._version, str(t.device), t.dtype) for t in src)
+    ver = tuple(None if t is None else (t._version, t.data_ptr(), str(t.device), t.dtype) for t in src)
     key = (id(att), id(pool))
     hit = _fold_cache.get(key)
-    if hit is not None and hit[0] == fp:
-        return hit[1], hit[2]
+    if hit is not None and hit[1] == ver and all((r is None and t is None) or (r is not None and r() is t)
+                                                 for r, t in zip(hit[0], src)):
+        return hit[2], hit[3]
     ap, keep_a = mha_params(att)
     pp, keep_p = additive_params(pool)
     dev = pool.fc1.weight.device
@@ -367,7 +414,7 @@ def folded_fc1(att, pool):
     check(l.xnrs_fold_weights(C.byref(ap), C.byref(pp), D, ptr(w1f), ptr(b1f), ptr(ws), nws, stream_ptr(dev)), "xnrs_fold_weights")
     if len(_fold_cache) > 64:  # modules come and go (tests): keep the table small
         _fold_cache.clear()
-    _fold_cache[key] = (fp, w1f, b1f)
+    _fold_cache[key] = (tuple(None if t is None else weakref.ref(t) for t in src), ver, w1f, b1f)
     return w1f, b1f
 
 

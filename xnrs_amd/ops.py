@@ -337,6 +337,25 @@ def _needs_grad(*tensors_or_modules) -> bool:
     return False
 
 
+#: Optional DEVICE word (int64 tensor of one element) that the attention kernels add to every dropout seed
+#: (include/xnrs_hip.h: xnrs_mha_params::seed_dev).  A grad step captured in a hipGraph bakes the host seeds into the graph;
+#: a caller that increments this word INSIDE the captured step (`word.add_(1)`) gets a fresh attention-dropout draw per
+#: replay, as the reference draws one per call (layers.py:148).  None (default): host seeds alone.
+_DROPOUT_SEED_WORD = None
+
+
+def set_dropout_seed_word(word):
+    """word: None, or a one-element int64 tensor on the HIP device.  Do not change it between a forward and its backward."""
+    global _DROPOUT_SEED_WORD
+    if word is not None and not (isinstance(word, torch.Tensor) and word.is_cuda and word.dtype == torch.int64 and word.numel() == 1):
+        raise hip.XnrsHipError("the dropout seed word is a one-element int64 tensor on the HIP device")
+    _DROPOUT_SEED_WORD = word
+
+
+def dropout_seed_word():
+    return _DROPOUT_SEED_WORD
+
+
 def _att_dropout(att):
     """(p, seed) of the attention-probability dropout (layers.py:117,148): active in train mode only.
     The seed is drawn from torch's CPU generator so torch.manual_seed() controls it."""
