@@ -31,6 +31,11 @@ import subprocess
 import sys
 import time
 
+# hipGraph replays (extra.*.hipgraph_replay): ROCm 7.2's graph packet-capture path returned stale data between kernel nodes on
+# gfx950 (tools/debug_graph_step.py); read by the runtime when it loads, so set before torch is imported.
+# It has no effect on the eager launches that every headline number is measured with.
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -397,7 +402,30 @@ TRAIN_W = dict(B=64, H=25, C=5, S=50, D=768, h=16, E=256, A=256)
 TRAIN_MODELS = {"nrms": "NRMS", "standard": "standard", "naml": "NAML"}
 
 
-def make_train_job(model_name, device, seed=7, dist_factory=None):
+class _StubRec(torch.nn.Module):
+    """Launcher self-test only (--selftest-backend gloo --train ...): a CPU stand-in with ParentRec's two entry points, so
+    that the data-parallel plumbing of the training line (weight broadcast, shard layout, embedding all-gather, gradient
+    bucket all-reduce, the JSON line) runs without a GPU.  No hot-path work is done or claimed."""
+
+    def __init__(self, d, e):
+        super().__init__()
+        self.news = torch.nn.Linear(d, e)
+        self.user = torch.nn.Linear(e, e)
+
+    def _vec(self, feat):
+        x, m = feat
+        return self.news((x * m).sum(2) / (m.sum(2) + 1e-8))
+
+    def get_user_embeddings(self, batch):
+        return self.user(self._vec(batch["user_features"]["history"]["title_emb"]).mean(1))
+
+    def forward(self, batch):
+        u = self.get_user_embeddings(batch)
+        c = self._vec(batch["candidate_features"]["title_emb"])
+        return torch.bmm(c, u.unsqueeze(2))
+
+
+def make_train_job(model_name, device, seed=7, dist_factory=None, stub=False):
     """Model, synthetic batch and the grad step of the reference (ContrastiveRankingTrainer._train_step,
     training.py:402-431) IN THE REFERENCE'S CALL ORDER: preds = model(batch) -> relu/MSE (training.py:388-392); user
     embeddings = model.get_user_embeddings(batch), i.e. a SECOND history encode (training.py:409, parent.py:49-81); InfoNCE
@@ -405,15 +433,29 @@ def make_train_job(model_name, device, seed=7, dist_factory=None):
     projection and one dW product per projection for NRMS (the attention-dropout draws differ), the whole deterministic
     encode for StandardRec / NAML (no dropout anywhere: bit-identical outputs; tests/test_hip_train_step.py).
     dist_factory: None, or model -> (distributed module, ShardLayout, GradBucket, n_global) for the data-parallel job."""
-    from xnrs_amd.losses import contrastive_loss as infonce  # fused HIP forward/backward (training.py:433-472)
     w = TRAIN_W
     name = TRAIN_MODELS.get(model_name, model_name)
-    model, _ = build_model(w, device, model_name=name)
+    if stub:  # launcher self-test on CPU: tiny shapes, a stand-in model and a stand-in for the fused InfoNCE
+        w = dict(w, B=4, H=3, C=2, S=4, D=8, E=8)
+        name = "stub"
+        torch.manual_seed(1234)
+        model = _StubRec(w["D"], w["E"]).to(device)
+
+        def infonce(e, labels, t):
+            return (e @ e.t() / t).logsumexp(1).mean()
+    else:
+        from xnrs_amd.losses import contrastive_loss as infonce  # fused HIP forward/backward (training.py:433-472)
+        model, _ = build_model(w, device, model_name=name)
     model.train()
     dist = dist_factory(model) if dist_factory is not None else None
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
     B, H, C, S, D = w["B"], w["H"], w["C"], w["S"], w["D"]
-    hist, cand = make_inputs(w, device, seed=seed)
+    if stub:
+        g = torch.Generator().manual_seed(seed)
+        hist = (torch.randn(B, H, S, D, generator=g), torch.ones(B, H, S, 1))
+        cand = (torch.randn(B, C, S, D, generator=g), torch.ones(B, C, S, 1))
+    else:
+        hist, cand = make_inputs(w, device, seed=seed)
     hfeat, cfeat = {"title_emb": hist}, {"title_emb": cand}
     if name == "NAML":  # title + abstract token tensors, category / subcategory ids (naml.py:61-112)
         gen = torch.Generator(device=device)
@@ -432,6 +474,7 @@ def make_train_job(model_name, device, seed=7, dist_factory=None):
     gen.manual_seed(seed + 1000)
     labels = torch.randint(0, 6, (B,), device=device, generator=gen)
     batch = {"user_features": {"history": hfeat, "other": {}}, "candidate_features": cfeat}
+    w_ = w  # (the closure below reads the job's own shapes)
 
     def fn(step_opt=True):
         if dist is not None:
@@ -445,7 +488,7 @@ def make_train_job(model_name, device, seed=7, dist_factory=None):
         if dist is not None:  # two collectives, no host sync: [embedding | label bits] all-gather + flat gradient all-reduce
             D_, layout, bucket, n_global = dist
             ue_all, lab_all = D_.gather_embeddings_and_labels(ue, labels, layout)
-            loss = D_.global_train_loss(rec, B, n_global, infonce(ue_all, lab_all, 0.08), 0.1)
+            loss = D_.global_train_loss(rec, w_["B"], n_global, infonce(ue_all, lab_all, 0.08), 0.1)
         else:
             loss = rec + 0.1 * infonce(ue, labels, 0.08)
         loss.backward()
@@ -849,7 +892,8 @@ def train_scaling(args, device, rank, world, dist_on):
     relu/MSE on the local impressions, InfoNCE over the GLOBAL batch (differentiable all-gather of the user embeddings +
     labels), backward, one flat SUM all-reduce of the gradients, Adam."""
     from xnrs_amd import distributed as D
-    w = TRAIN_W
+    stub = args.selftest_backend is not None  # launcher self-test: CPU stand-in model over gloo (tests/test_bench_launcher.py)
+    w = dict(TRAIN_W, B=4) if stub else TRAIN_W
     n_global = w["B"] * (world if dist_on else 1)
     # once per run: weights broadcast from rank 0, the shard layout (fixed per-rank batch -> no communication) and the
     # persistent gradient bucket
@@ -857,14 +901,16 @@ def train_scaling(args, device, rank, world, dist_on):
         D.broadcast_parameters(model)
         return (D, D.ShardLayout.uniform(w["B"]), D.GradBucket(model.parameters()), n_global)
     model, opt, batch, targets, labels, fn = make_train_job(args.train, device, seed=2000 + rank,
-                                                            dist_factory=factory if dist_on else None)
-    dt = timed(fn, args.steps, args.warmup, dist_on)
+                                                            dist_factory=factory if dist_on else None, stub=stub)
+    dt = timed(fn, args.steps, args.warmup, dist_on, device=device)
     n_gpus = world if dist_on else 1
-    roof = train_roofline(fn, dt / args.steps)  # every rank runs the profiled step (it contains the collectives)
+    # every rank runs the profiled step (it contains the collectives)
+    roof = None if stub else train_roofline(fn, dt / args.steps)
     return {"roofline": roof, "metric": "train impressions/sec (forward + second history encode + loss + backward + gradient all-reduce + Adam)",
             "value": n_global * args.steps / dt, "unit": "impressions/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": GEMM_MODES[args.gemm_mode][0], "data": "synthetic", "build_id": hip.build_id(),
+            "vs_baseline": None, "dtype": GEMM_MODES[args.gemm_mode][0], "data": "stub" if stub else "synthetic",
+            "build_id": None if stub else hip.build_id(),
             "config": {"workload": f"{args.train} grad step in the reference's call order (model(batch) + get_user_embeddings(batch): "
                                    "two history encodes, training.py:402-431), 64 impressions per GPU (H=25, C=5, S=50, D=768), global "
                                    "in-batch InfoNCE (lambda 0.1, tau 0.08), train mode (NRMS: attention dropout 0.1)",
@@ -905,6 +951,19 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with --nproc-per-node {args.gpus} "
               f"(or without a launcher: bench.py starts the ranks itself)", file=sys.stderr)
         sys.exit(2)
+    if args.selftest_backend and args.train:
+        # the TRAINING line's launcher path on CPU: process group, rank count, weight broadcast, shard layout, embedding
+        # all-gather, gradient-bucket all-reduce and the JSON line -- with a stand-in model (no hot-path work)
+        torch.distributed.init_process_group(args.selftest_backend, rank=rank, world_size=world)
+        ranks = count_ranks("cpu")
+        out = train_scaling(args, torch.device("cpu"), rank, world, True)
+        out["rccl_ranks"] = ranks
+        out["metric"] = "launcher self-test of the training line (stub model, no hot-path work)"
+        if rank == 0:
+            print(json.dumps(out))
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+        return
     if args.selftest_backend:
         selftest_line(args, rank, world)
         return

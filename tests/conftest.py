@@ -1,6 +1,11 @@
 import os
 import sys
 
+# hipGraph replays of multi-kernel steps came out wrong with ROCm 7.2's graph "packet capture" path on gfx950 (stale reads
+# between kernel nodes; tools/debug_graph_step.py); the runtime reads this switch when it is loaded, i.e.
+# before the first `import torch`
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

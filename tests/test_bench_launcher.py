@@ -55,3 +55,19 @@ def test_a_dying_rank_stops_the_job():
     barrier: the parent must notice, stop rank 1 and report a non-zero exit instead of hanging."""
     p = _run(["--gpus", "2", "--steps", "0", "--selftest-backend", "gloo"])
     assert p.returncode != 0
+
+
+@pytest.mark.timeout(300)
+def test_train_line_launcher_path_over_gloo():
+    """`bench.py --gpus 2 --train nrms`: the same spawn / rendezvous / rank count as the forward line, then the training
+    line's own plumbing -- weights broadcast from rank 0, uniform shard layout, ONE embedding all-gather and ONE gradient
+    bucket all-reduce per step, MAX-over-ranks timing -- with a CPU stand-in model over gloo; rank 0 prints one line."""
+    p = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--train", "nrms", "--selftest-backend", "gloo"])
+    assert p.returncode == 0, p.stderr
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["data"] == "stub"
+    assert out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak" and out["loss_finite"] is True
+    assert out["unit"] == "impressions/s" and out["value"] > 0 and out["ms_per_step"] > 0
+    assert "two history encodes" in out["config"]["workload"] and "all-reduce" in out["config"]["parallelism"]

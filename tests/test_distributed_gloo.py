@@ -159,3 +159,33 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
+
+
+def _eval_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xnrs_amd.evaluation import _dist_rank_world, sharded_mean
+    r, w, on = _dist_rank_world(None)
+    assert (r, w, on) == (rank, world, True)
+    per = torch.arange(37 * 9, dtype=torch.float64).reshape(37, 9).sin()  # per-impression metric rows of a 37-session epoch
+    lo, hi = D.shard_range(37, rank, world)
+    mean = sharded_mean(per[lo:hi].sum(0), 37, on)
+    out[rank] = mean
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_rank_sharded_metric_mean(world):
+    """The reduction of the rank-sharded evaluation epoch (xnrs_amd.evaluation.evaluate): contiguous session blocks per rank
+    (uneven: 37 sessions), ONE fp64 all-reduce of the per-rank sums, every rank ends with the single-process mean.  (The
+    kernels of the epoch need a GPU: tests/test_hip_two_ranks.py runs the whole evaluate() with 2 and 4 ranks.)"""
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_eval_worker, args=(world, port, out), nprocs=world, join=True)
+        per = torch.arange(37 * 9, dtype=torch.float64).reshape(37, 9).sin()
+        ref = per.sum(0) / 37
+        for r in range(world):
+            assert torch.allclose(out[r], ref, rtol=1e-13, atol=1e-15), r

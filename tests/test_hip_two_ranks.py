@@ -107,3 +107,48 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_step():
     for k, g in ref.items():
         scale = max(g.abs().max().item(), 1e-3 * gmax)
         assert (got["grads"][k] - g).abs().max().item() / scale <= 1e-4, k
+
+
+def _eval_rank(rank, world, port, path):
+    import torch.distributed as dist
+
+    from xnrs_amd import distributed as D
+    from xnrs_amd.evaluation import evaluate
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    store, beh = _world()
+    store, beh = store.to(dev), beh.to(dev)
+    model = _model(dev)
+    D.broadcast_parameters(model)
+    res = evaluate(model, store, beh, l_hist=8, batch=16)  # several batches per rank, a ragged last one
+    torch.save(res, f"{path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 4])
+def test_rank_sharded_evaluation_equals_the_single_process_epoch(world):
+    """evaluate() under a process group: news table encoded in slices + one all-gather, sessions split by shard_range, one
+    fp64 all-reduce of the metric sums (the reference's test loop, training.py:194-243, is one process at batch size 1) --
+    every rank returns the single-process metrics (uneven shards: 121 table rows, 64 sessions over 4 ranks of batch 16)."""
+    import torch.multiprocessing as mp
+
+    from xnrs_amd.evaluation import evaluate
+    dev = torch.device("cuda", 0)
+    store, beh = _world()
+    store, beh = store.to(dev), beh.to(dev)
+    ref = evaluate(_model(dev), store, beh, l_hist=8, batch=16, distributed=False)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "res")
+        mp.spawn(_eval_rank, args=(world, port, path), nprocs=world, join=True)  # <= 4 GPU processes + this one
+        got = [torch.load(f"{path}.{r}", weights_only=True) for r in range(world)]
+    for res in got:
+        assert res.keys() == ref.keys()
+        for k in ref:
+            assert abs(res[k] - ref[k]) <= 1e-9 * max(1.0, abs(ref[k])), (k, res[k], ref[k])
+    assert all(g == got[0] for g in got)  # every rank holds the same dict

@@ -1,5 +1,8 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-for i in 1 2 3 4; do python -m pytest tests/test_hip_train_step.py -q 2>&1 | tail -n 1; done
+echo "--- packet capture off + NO cache workarounds"
+DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 XNRS_HIP_LIB=$GRAFT_REPO_ROOT/xnrs_amd/libxnrs_hip_nowa.so python tools/debug_graph_step.py 8 2>&1 | tail -n 4 | cut -c1-200
+DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 XNRS_HIP_LIB=$GRAFT_REPO_ROOT/xnrs_amd/libxnrs_hip_nowa.so NOCLEAR=1 python tools/debug_graph_step.py 8 2>&1 | tail -n 4 | cut -c1-200
+echo "--- full gpu suite (conftest sets packet capture off)"
 python -m pytest tests -m gpu -q 2>&1 | tail -n 12 > gpurun_out/r4_gpu_suite.log; tail -n 3 gpurun_out/r4_gpu_suite.log
-python tools/bench_train.py > gpurun_out/r4_train.log 2>&1; cut -c1-100 gpurun_out/r4_train.log | tail -n 5
+for i in 1 2 3; do python -m pytest tests/test_hip_train_step.py -q 2>&1 | tail -n 1; done

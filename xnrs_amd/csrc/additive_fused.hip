@@ -66,7 +66,6 @@ __device__ __forceinline__ float af_wave_sum(float v) {  // = pool_score.hip wav
 // PP = (news, column chunk) pairs per thread in the pooling phase: ceil(nn * D/4 / 512); AF_FBUF = fragment register sets
 template <int PP, int AF_FBUF>
 __global__ __launch_bounds__(AF_T, AF_WAVES / 4) void additive_fused_kernel(AdditiveFusedArgs a, int nn, int n_tiles) {
-  XNRS_KERNEL_ENTRY();
   __shared__ __attribute__((aligned(16))) float As[2][AF_BM * AF_BK];
   __shared__ __attribute__((aligned(16))) float Bs[2][AF_BN * AF_BK];
   __shared__ float s_ep[AF_BM * AF_EPS];

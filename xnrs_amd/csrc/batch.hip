@@ -26,7 +26,6 @@ __device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t a, uint64_t b)
 
 // one thread per output id
 __global__ __launch_bounds__(256) void assemble_train_kernel(BatchArgs a) {
-  XNRS_KERNEL_ENTRY();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int W = a.l_hist + 1 + a.n_neg;
   if (i >= a.B * W) return;
@@ -61,7 +60,6 @@ hipError_t launch_assemble_train(const BatchArgs& a, hipStream_t stream) {
 
 // one wave per impression: history ids + candidate CSR fill (offsets computed by the caller)
 __global__ __launch_bounds__(256) void assemble_eval_kernel(BatchArgs a) {
-  XNRS_KERNEL_ENTRY();
   const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= a.B) return;
   const int lane = threadIdx.x & 63;
@@ -90,7 +88,6 @@ hipError_t launch_assemble_eval(const BatchArgs& a, hipStream_t stream) {
 // r[e] = <vecs[cand_rows[e], :], u[cand_sess[e], :]> : one wave per candidate entry
 __global__ __launch_bounds__(256) void score_csr_kernel(const float* vecs, const int32_t* rows, const int32_t* sess, const float* u,
                                                          float* r, int64_t n, int E, int relu) {
-  XNRS_KERNEL_ENTRY();
   const int64_t e = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (e >= n) return;
   const int lane = threadIdx.x & 63;
@@ -116,7 +113,6 @@ hipError_t launch_score_csr(const float* vecs, const int32_t* rows, const int32_
 // tie order is unspecified).  out[b, :] = {ndcg@5, ndcg@10, rr, ctr@1, ctr@10, auc, acc, rec, prec}.
 __global__ __launch_bounds__(256) void rank_metrics_kernel(const float* score, const float* target, const int64_t* off, float* out,
                                                             int64_t B) {
-  XNRS_KERNEL_ENTRY();
   const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
   const int lane = threadIdx.x & 63;
@@ -202,7 +198,6 @@ hipError_t launch_rank_metrics(const float* score, const float* target, const in
 template <bool VEC>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids,
                                                            float* __restrict__ out, int64_t row_floats, int pieces) {
-  XNRS_KERNEL_ENTRY();
   const int64_t row = blockIdx.x / pieces;
   const int piece = (int)(blockIdx.x - row * pieces);
   const int64_t src = (int64_t)ids[row] * row_floats, dst = row * row_floats;
@@ -258,7 +253,6 @@ __global__ __launch_bounds__(1024) void compact_rows_kernel(const float* __restr
                                                              int64_t n_news, int64_t chunk, int S, int64_t* __restrict__ row_off_all,
                                                              int32_t* __restrict__ live_all, int32_t* __restrict__ kvs_all,
                                                              int32_t* __restrict__ kvb_all, int64_t* __restrict__ counts_all) {
-  XNRS_KERNEL_ENTRY();
   __shared__ int s_cnt[1024];
   __shared__ int s_ex[2][1024];
   __shared__ int s_wsum[2][16];
@@ -359,7 +353,6 @@ __global__ __launch_bounds__(1024) void compact_rows64_kernel(const float* __res
                                                                int64_t n_news, int64_t chunk, int S, int64_t* __restrict__ row_off_all,
                                                                int32_t* __restrict__ live_all, int32_t* __restrict__ kvs_all,
                                                                int32_t* __restrict__ kvb_all, int64_t* __restrict__ counts_all) {
-  XNRS_KERNEL_ENTRY();
   __shared__ unsigned long long s_bits[1024];
   __shared__ int64_t s_row[1024];
   __shared__ int s_ex[2][1024];
@@ -457,7 +450,6 @@ __global__ __launch_bounds__(1024) void compact_rows64_kernel(const float* __res
 //           lists torch.nonzero gave.
 __global__ __launch_bounds__(256) void row_counts_kernel(const float* __restrict__ mask, const int32_t* __restrict__ ids,
                                                           int64_t n_seq, int L, int32_t* __restrict__ cnt) {
-  XNRS_KERNEL_ENTRY();
   const int lane = threadIdx.x & 63;
   const int64_t seq = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (seq >= n_seq) return;
@@ -473,7 +465,6 @@ __global__ __launch_bounds__(1024) void row_lists_kernel(const float* __restrict
                                                           int32_t* __restrict__ live, int32_t* __restrict__ live_src,
                                                           int32_t* __restrict__ kv, int32_t* __restrict__ kv_src,
                                                           int64_t* __restrict__ counts) {
-  XNRS_KERNEL_ENTRY();
   __shared__ int s_red[2][16];
   __shared__ int s_base[2];
   __shared__ int s_ex[2][RL_SEQ];
@@ -567,7 +558,6 @@ hipError_t launch_build_row_lists(const float* mask, const int32_t* ids, int64_t
 
 // NaN over a result whose precondition turned out violated on the device (the flags of every pass, OR-ed)
 __global__ __launch_bounds__(256) void poison_kernel(float* y, int64_t n, const int64_t* flags, int n_flags, int flag_stride) {
-  XNRS_KERNEL_ENTRY();
   bool bad = false;
   for (int i = 0; i < n_flags; ++i) bad = bad || flags[(int64_t)i * flag_stride] != 0;
   if (!bad) return;

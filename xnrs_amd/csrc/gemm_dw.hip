@@ -53,7 +53,6 @@ __device__ __forceinline__ int dw_lds_off(int row, int chunk) {  // float offset
 
 template <int KG>
 __global__ __launch_bounds__(256, 3) void gemm_dw_kernel(GemmArgs a, int n_tiles, int tiles, int nsplit) {
-  XNRS_KERNEL_ENTRY();
   __shared__ __attribute__((aligned(16))) float As[2][DW_BM * DW_BK];
   __shared__ __attribute__((aligned(16))) float Bs[2][DW_BN * DW_BK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -236,7 +235,6 @@ constexpr int DW2_BM = 256, DW2_BN = 256;
 
 template <int KG>
 __global__ __launch_bounds__(512, 2) void gemm_dw256_kernel(GemmArgs a, int n_tiles, int tiles, int nsplit) {
-  XNRS_KERNEL_ENTRY();
   __shared__ __attribute__((aligned(16))) float As[2][DW2_BM * DW_BK];
   __shared__ __attribute__((aligned(16))) float Bs[2][DW2_BN * DW_BK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

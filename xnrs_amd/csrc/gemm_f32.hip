@@ -86,7 +86,6 @@ constexpr unsigned BUF_OOB = 0x40000000u;
 template <int TM, int TN, bool A_COL, bool B_KN, bool VEC, int PIPE, int BK, bool BUF = false, int MINW = 2, bool GATH = false,
           int KG = 2, bool RDOT = false, bool MDEV = false>
 __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmArgs a, int m_tiles, int n_tiles_seg, int gn) {
-  XNRS_KERNEL_ENTRY();
   static_assert(!MDEV || (!A_COL && !B_KN), "device row counts: forward layout only");
   static_assert(!BUF || (!A_COL && !B_KN && VEC), "buffer loads are implemented for the forward layout");
   static_assert(!RDOT || PIPE == 5, "the fused row dots ride on the interleaved pipeline (its MFMA call is the swapped one)");
@@ -673,7 +672,6 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_kernel(const GemmArgs a, i
 
 // Wt[c][r] = W[r][c]: 32x32 tiles through LDS (padded rows), both sides coalesced
 __global__ __launch_bounds__(256) void transpose_kernel(const float* W, float* Wt, int rows, int cols) {
-  XNRS_KERNEL_ENTRY();
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
@@ -693,7 +691,6 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* W, float* W
 // zero `width` floats (multiple of 4, 16-byte aligned) of each of `rows` rows of pitch `ld` floats: the column block of
 // one segment inside a [rows, 3D] image.  (hipMemset2DAsync took 311 us for 80 000 x 768 floats, this runs at HBM speed.)
 __global__ __launch_bounds__(256) void zero_cols_kernel(float* p, int64_t ld, int w4, int64_t n4) {
-  XNRS_KERNEL_ENTRY();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   const int64_t r = i / w4;
@@ -716,7 +713,6 @@ hipError_t launch_zero_cols(float* p, int64_t ld, int width, int64_t rows, hipSt
 // grad step's 80 000 x 2304 image (zero_cols over the whole image: 0.14 ms per encode).
 __global__ __launch_bounds__(256) void zero_dead_qkv_kernel(float* qkv, const float* __restrict__ mask,
                                                             const int32_t* __restrict__ ids, int L, int D4) {
-  XNRS_KERNEL_ENTRY();
   const int64_t seq = blockIdx.x;
   const float* mp = mask + (ids ? (int64_t)ids[seq] : seq) * L;
   int any = 0;
@@ -753,7 +749,6 @@ hipError_t launch_transpose(const float* W, float* Wt, int rows, int cols, hipSt
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, int64_t slab_stride, int nsplit, float* C,
                                                              int64_t n, int accumulate, const float* cs_partial, float* cs_out,
                                                              int cs_n, float* C2, int64_t n1, float* cs_out2, int cs_n1) {
-  XNRS_KERNEL_ENTRY();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) {
     const int64_t c = i - n;

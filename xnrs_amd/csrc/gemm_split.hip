@@ -49,7 +49,6 @@ __device__ __forceinline__ float hi_f32(unsigned p) { return __uint_as_float(p &
 
 template <int NPL, bool BUF, int MINW, bool BPRE = false>
 __global__ __launch_bounds__(256, MINW) void gemm_split_kernel(GemmArgs a, int m_tiles, int n_tiles_seg, int gn) {
-  XNRS_KERNEL_ENTRY();
   constexpr int BM = 128, BN = 128, BK = 16;
   constexpr int NPROD = NPL == 3 ? 6 : 3;
   // product p multiplies plane PA[p] of A with plane PB[p] of B; the biggest term first so the first MFMA
@@ -303,7 +302,6 @@ __global__ __launch_bounds__(256, MINW) void gemm_split_kernel(GemmArgs a, int m
 
 // planes[p][k/16][n][16] of W[n][k]: the exact 3-way bf16 split (same arithmetic as split_phase), zero padded to ldp columns
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* W, int64_t N, int64_t K, int64_t ldp, unsigned short* planes) {
-  XNRS_KERNEL_ENTRY();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one thread per PAIR of k
   const int64_t pairs = ldp / 2;
   if (i >= N * pairs) return;

@@ -22,7 +22,6 @@ __device__ __forceinline__ float wsum(float v) {
 
 // en[i,:] = x[i,:] / max(||x_i||, eps); inv[i] = 1 / max(||x_i||, eps): one wave per row
 __global__ __launch_bounds__(256) void infonce_normalize_kernel(const float* x, float* en, float* inv, int64_t B, int E) {
-  XNRS_KERNEL_ENTRY();
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= B) return;
   const int lane = threadIdx.x & 63;
@@ -37,7 +36,6 @@ __global__ __launch_bounds__(256) void infonce_normalize_kernel(const float* x, 
 // one workgroup per row i: num_i, den_i, L_i
 __global__ __launch_bounds__(256) void infonce_row_kernel(const float* en, const int64_t* lab, float* num, float* den, float* li,
                                                            int64_t B, int E, float inv_t) {
-  XNRS_KERNEL_ENTRY();
   __shared__ float s_e[1024];
   __shared__ float s_red[8];
   const int64_t i = blockIdx.x;
@@ -72,7 +70,6 @@ __global__ __launch_bounds__(256) void infonce_row_kernel(const float* en, const
 
 // loss = sum_i L_i / (count + 1e-8); single workgroup, ordered
 __global__ __launch_bounds__(256) void infonce_final_kernel(const float* li, const float* num, float* loss, float* scale, int64_t B) {
-  XNRS_KERNEL_ENTRY();
   __shared__ float s_l[256];
   __shared__ float s_c[256];
   float l = 0.f, c = 0.f;
@@ -100,7 +97,6 @@ __global__ __launch_bounds__(256) void infonce_final_kernel(const float* li, con
 __global__ __launch_bounds__(256) void infonce_bwd_kernel(const float* en, const float* inv, const int64_t* lab, const float* num,
                                                            const float* den, const float* scale, const float* gout, float* dx,
                                                            int64_t B, int E, float inv_t) {
-  XNRS_KERNEL_ENTRY();
   __shared__ float s_e[1024];
   __shared__ float s_acc[4][1024];
   __shared__ float s_red[4];

@@ -43,29 +43,13 @@ struct Knobs {
 const Knobs& knobs();
 void reload_knobs();
 
-// First statement of EVERY kernel of the library: invalidate the scalar data cache (one SALU instruction per wave; the memory
-// clobber keeps the compiler from hoisting data loads above it).  Observed on gfx950 / ROCm 7.2 with a grad step replayed
-// as a hipGraph (tools/debug_graph_step.py): wave-uniform reads that hipcc turns into SCALAR loads -- the device row count
-// of a list (GemmArgs::m_dev / k_dev), a mask row, a per-sequence scalar -- returned what an EARLIER tensor had held at the
-// same address (memory the graph's allocator pool had reused: the second replay came out NaN for about one batch in
-// three); with the invalidate and the agent-scope count load below, 64 of 64 replays equal the eager step bit for bit.
-// Ordinary launches are unaffected either way (the dispatch packet's acquire fence invalidates the cache).
-// -DXNRS_NO_CACHE_WORKAROUNDS builds the library without both, to reproduce the observation.
-#ifdef XNRS_NO_CACHE_WORKAROUNDS
-#define XNRS_KERNEL_ENTRY() ((void)0)
-#else
-#define XNRS_KERNEL_ENTRY() asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory")
-#endif
-// A device scalar written by an EARLIER kernel on the same stream (the row counts of device-built lists), read with an
-// agent-scope load (global_load ... sc1: served by L2, past the scalar and vector L1 caches) instead of the scalar load a
-// plain `*p` compiles to.
-__device__ __forceinline__ int64_t load_dev_scalar(const int64_t* p) {
-#ifdef XNRS_NO_CACHE_WORKAROUNDS
-  return *p;
-#else
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-}
+// A device scalar written by an EARLIER kernel on the same stream (the row counts of device-built lists, GemmArgs::m_dev /
+// k_dev): wave-uniform, one load per workgroup.
+// (hipGraph note, round 4: replays of the grad step read stale values here -- and in other wave-uniform reads -- under ROCm
+// 7.2's graph "packet capture" path on gfx950; invalidating the scalar cache at kernel entry and an agent-scope load here
+// reduced but did not remove it, DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 removed it with or without them (128 of 128 replays equal
+// to the eager step: tools/debug_graph_step.py), so the kernels carry no workaround.)
+__device__ __forceinline__ int64_t load_dev_scalar(const int64_t* p) { return *p; }
 
 // ---------------------------------------------------------------- Linear (fp32 MFMA GEMM)
 // C[M, nseg*Nseg] = act(A[M,K] . W_s[Nseg,K]^T + bias_s), s = column segment (up to 3 weights

@@ -28,7 +28,6 @@ constexpr int MAX_FT = 8;  // d_k <= 128
 // d_k products in index order.  (The first version gave every (row, head) to one thread reading 192-B pieces
 // 3 KB apart: 1 981 us for 80 000 rows; this form is bandwidth-bound.)
 __global__ __launch_bounds__(256) void mha_delta_kernel(MhaBwdArgs a, int64_t n_rows) {
-  XNRS_KERNEL_ENTRY();
   __shared__ float s_p[2048];
   const int D = a.n_heads * a.d_k;
   for (int64_t row = blockIdx.x; row < n_rows; row += gridDim.x) {
@@ -74,7 +73,6 @@ __device__ __forceinline__ void store4(float* p, int f0, int lim, bool vec, f32x
 
 template <int KT, bool VEC>
 __global__ __launch_bounds__(256) void mha_dq_kernel(MhaBwdArgs a, int QT, int64_t n_units) {
-  XNRS_KERNEL_ENTRY();
   const int lane = threadIdx.x & 63;
   const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (unit >= n_units) return;
@@ -176,7 +174,6 @@ __global__ __launch_bounds__(256) void mha_dq_kernel(MhaBwdArgs a, int QT, int64
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void mha_dkdv_kernel(MhaBwdArgs a, int KTn, int64_t n_units) {
-  XNRS_KERNEL_ENTRY();
   const int lane = threadIdx.x & 63;
   const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (unit >= n_units) return;
@@ -309,7 +306,6 @@ constexpr int BWD_TLD = 20;  // row stride of the dS transpose tile
 
 template <int NFB>
 __global__ __launch_bounds__(256) void mha_bwd_fused_kernel(MhaBwdArgs a) {
-  XNRS_KERNEL_ENTRY();
   // LDS row stride (floats) of the Q / dO / partial-dQ images: 16*NFB + 4 keeps 16 consecutive rows on 16 distinct
   // 16-byte bank groups (20, 36, 52, 68 floats) and 4 rows apart on banks +16
   constexpr int BWD_LD = 16 * NFB + 4;

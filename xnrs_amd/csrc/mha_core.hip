@@ -26,7 +26,6 @@ namespace xnrs {
 
 template <int KT, bool VEC>
 __global__ __launch_bounds__(256) void mha_core_kernel(MhaCoreArgs a, int QT, int64_t n_units) {
-  XNRS_KERNEL_ENTRY();
   const int lane = threadIdx.x & 63;
   const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (unit >= n_units) return;  // wave-uniform
@@ -174,7 +173,6 @@ __global__ __launch_bounds__(256) void mha_core_kernel(MhaCoreArgs a, int QT, in
 // mha_core_kernel (bitwise identical results).
 template <int KT, int NFB>
 __global__ __launch_bounds__(256) void mha_core_head_kernel(MhaCoreArgs a, int64_t n_units) {
-  XNRS_KERNEL_ENTRY();
   const int lane = threadIdx.x & 63;
   const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (unit >= n_units) return;  // wave-uniform
@@ -319,7 +317,6 @@ static hipError_t launch_head_kt(const MhaCoreArgs& a, hipStream_t stream) {
 // parallel, and a wave needs ~64 instead of 176 VGPRs (6 instead of 2 waves per SIMD to hide latency).
 template <int KT, int NFB, int QTP>
 __global__ __launch_bounds__(256) void mha_core_lds_kernel(MhaCoreArgs a, int64_t n_pairs) {
-  XNRS_KERNEL_ENTRY();
   constexpr int G = 4 / QTP;          // pairs per workgroup
   constexpr int NTHR = QTP * 64;      // threads per pair
   constexpr int NSLOT = KT * NFB * 64;
@@ -496,7 +493,6 @@ static hipError_t launch_lds(const MhaCoreArgs& a, hipStream_t stream) {
 // hide behind.
 template <int KTM, int NFB, bool TAIL, bool DROP>
 __global__ __launch_bounds__(256, (KTM * NFB <= 9 ? 8 : 5)) void mha_core_pair_kernel(MhaCoreArgs a) {
-  XNRS_KERNEL_ENTRY();
   constexpr int NSLOT = KTM * NFB * 64;
   constexpr int NCH = NFB * 4;        // 16-byte chunks per padded row
   constexpr int KP = 256 / NCH;       // keys staged per pass

@@ -85,7 +85,6 @@ struct NfImg {
 // image[ks][wave][t][lane][j] = W[16 (wave + NWAVE t) + (lane & 15)][16 ks + 4 (lane >> 4) + j], zero outside W
 // (NWAVE = 8 for the Q|K|V and fc1 images, 4 for the out-projection image)
 __global__ __launch_bounds__(256) void news_fused_prep_kernel(NewsFusedArgs a, NfImg im, int HG, float* img) {
-  XNRS_KERNEL_ENTRY();
   const int D = a.D, dk = a.d_k, H = a.n_heads, A = a.A;
   const size_t n4 = im.off_bqkv(0) / 4;  // float4 slots of the three weight images
   const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -233,7 +232,6 @@ constexpr int NF_NSTAMP = 32;
 template <int DK4, int NPW, bool FOLD>
 __global__ __launch_bounds__(NF_THREADS, NPW == 1 ? 4 : 2) void news_fused_kernel(NewsFusedArgs a, NfImg im, const float* __restrict__ img, int HG,
                                                                    int LQ, int LY, int64_t n_wg) {
-  XNRS_KERNEL_ENTRY();
   constexpr int TR = 2 * NPW, TRC = NPW;  // 16-row tiles per workgroup (32 virtual rows per news); per wave in (c)
   constexpr int TF = NF_TF, TY = NF_TY, TA = NF_TA;
   constexpr int dk = 4 * DK4;  // head width: compile-time, so the attention core is one straight run of MFMAs

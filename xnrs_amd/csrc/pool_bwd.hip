@@ -25,7 +25,6 @@ constexpr int POOLB_MAX_N = 512;
 // of 150 + 50 four-byte ones; the scalar form ran at 2.4 TB/s of its own traffic, latency-bound on the per-row loops.
 template <bool VEC>
 __global__ __launch_bounds__(256) void additive_pool_bwd_kernel(AdditivePoolBwdArgs a) {
-  XNRS_KERNEL_ENTRY();
   __shared__ float s_a[POOLB_MAX_N];
   __shared__ float s_da[POOLB_MAX_N];
   __shared__ float s_red[4];
@@ -143,7 +142,6 @@ hipError_t launch_additive_pool_bwd(const AdditivePoolBwdArgs& a, hipStream_t st
 // y = sum_i x_i m_i / (sum m + 1e-8)  ->  dx_i = dy * m_i / (sum m + 1e-8)
 __global__ __launch_bounds__(256) void mean_pool_bwd_kernel(const float* dy, const float* mask, const int32_t* mask_ids,
                                                              float* dx, int64_t lddx, int N, int D) {
-  XNRS_KERNEL_ENTRY();
   __shared__ float s_red[4];
   const int64_t seq = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -176,7 +174,6 @@ constexpr int COLSUM_MAX_SPLITS = 4096;
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* X, int64_t ldx, const float* w, int64_t M, int N,
                                                               int64_t rows_per, float* partial, const float* X2, int64_t ldx2,
                                                               const float* w2, int64_t M1) {
-  XNRS_KERNEL_ENTRY();
   const int n = blockIdx.x * 256 + threadIdx.x;
   const int sp = blockIdx.y;
   const int64_t r0 = sp * rows_per;
@@ -204,7 +201,6 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* X, int
 
 // one wave per column: lane l adds partials l, l+64, ... in order, then a fixed shuffle tree
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, int nsplit, int N, float* out) {
-  XNRS_KERNEL_ENTRY();
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
   const int lane = threadIdx.x & 63;
@@ -252,7 +248,6 @@ hipError_t launch_colsum(const float* X, int64_t ldx, const float* w, int64_t M,
 // r[b,c] = <c[b,c,:], u[b,:]>  ->  du[b,e] = sum_c dr[b,c] c[b,c,e] ;  dc[b,c,e] = dr[b,c] u[b,e]
 __global__ __launch_bounds__(256) void dot_scoring_bwd_kernel(const float* u, const float* c, const float* dr, float* du,
                                                                float* dc, int64_t B, int C, int E) {
-  XNRS_KERNEL_ENTRY();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= B * E) return;
   const int64_t b = i / E;
@@ -273,7 +268,6 @@ __global__ __launch_bounds__(256) void dot_scoring_bwd_kernel(const float* u, co
 constexpr int DOTN_MAX_E = 1024;
 __global__ __launch_bounds__(256) void dot_scoring_norm_bwd_kernel(const float* u, const float* c, const float* dr, float* du,
                                                                     float* dc, int C, int E) {
-  XNRS_KERNEL_ENTRY();
   __shared__ float s_du[4][DOTN_MAX_E];
   const int64_t b = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -334,7 +328,6 @@ namespace xnrs {
 // no atomics; O(n_rows * M) index compares is negligible for tables of tens to hundreds of rows.
 __global__ __launch_bounds__(64) void embedding_grad_kernel(const float* d_rows, const int32_t* ids, int64_t M, int K,
                                                              float* d_table) {
-  XNRS_KERNEL_ENTRY();
   const int r = blockIdx.x;
   for (int k0 = 0; k0 < K; k0 += 64) {
     const int k = k0 + threadIdx.x;

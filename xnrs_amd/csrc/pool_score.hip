@@ -19,7 +19,6 @@ constexpr int POOL_MAX_N = 512;
 // a_i = exp(w2 . t_i + b2) * m_i / (sum_j exp(..)*m_j + 1e-8);  y = sum_i a_i x_i.
 // exp is NOT max-stabilised and the epsilon is 1e-8, exactly as layers.py:61-64.
 __global__ __launch_bounds__(256) void additive_pool_kernel(AdditivePoolArgs a) {
-  XNRS_KERNEL_ENTRY();
   __shared__ float s_w[POOL_MAX_N];
   __shared__ float s_red[4];
   const int64_t seq = blockIdx.x;
@@ -96,7 +95,6 @@ __global__ __launch_bounds__(256) void additive_pool_kernel(AdditivePoolArgs a) 
 }
 
 __global__ __launch_bounds__(256) void add_rowscaled_bias_kernel(float* p, int64_t ld, const float* s, const float* b, int64_t n, int D) {
-  XNRS_KERNEL_ENTRY();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n * D) return;
   const int64_t r = i / D;
@@ -105,7 +103,6 @@ __global__ __launch_bounds__(256) void add_rowscaled_bias_kernel(float* p, int64
 }
 
 __global__ __launch_bounds__(256) void fold_bias_kernel(const float* w1, const float* bo, const float* b1, float* bf, int A, int D) {
-  XNRS_KERNEL_ENTRY();
   const int a = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (a >= A) return;  // wave-uniform
   float acc = 0.f;
@@ -137,7 +134,6 @@ hipError_t launch_additive_pool(const AdditivePoolArgs& a, hipStream_t stream) {
 
 // y = sum_i x_i m_i / (sum_i m_i + 1e-8)
 __global__ __launch_bounds__(256) void mean_pool_kernel(MeanPoolArgs a) {
-  XNRS_KERNEL_ENTRY();
   __shared__ float s_m[POOL_MAX_N];
   __shared__ float s_red[4];
   const int64_t seq = blockIdx.x;
@@ -175,7 +171,6 @@ hipError_t launch_mean_pool(const MeanPoolArgs& a, hipStream_t stream) {
 // hm[n] = clamp(sum_s m[n,s], 0, 1): one wave per row
 __global__ __launch_bounds__(256) void collapse_mask_kernel(const float* m, const int32_t* ids, float* hm, int64_t n_rows,
                                                              int S) {
-  XNRS_KERNEL_ENTRY();
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n_rows) return;
   const int lane = threadIdx.x & 63;
@@ -197,7 +192,6 @@ hipError_t launch_collapse_mask(const float* m, const int32_t* ids, float* hm, i
 // r[b,c] = <c[b,c,:], u[b,:]>  (optionally both L2-normalised): one wave per (b,c)
 __global__ __launch_bounds__(256) void dot_scoring_kernel(const float* u, const float* c, float* r, int64_t n_pairs, int C,
                                                            int E, int normalize) {
-  XNRS_KERNEL_ENTRY();
   const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (pair >= n_pairs) return;
   const int lane = threadIdx.x & 63;
