@@ -411,6 +411,19 @@ int32_t xnrs_profile_read(double *ms, int64_t *launches, double *flops);
  * value at the forward and refuses the backward when it has changed (xnrs_amd/autograd.py does).  1 / 0. */
 int32_t xnrs_train_fold_enabled(void);
 
+/* ---- sticky device status word (ABI 6; no reference counterpart) ------------------------------------------
+ * Entry points that never synchronise cannot return an error for a precondition only the device can see.  They OR a bit
+ * into ONE caller-owned int32 device word instead (and keep their outputs recognisably wrong: NaN), which the caller reads
+ * at its next natural synchronisation point.  xnrs_set_status_word registers the word (process-global like the knobs;
+ * NULL: none -- the NaN outputs are then the only signal); the caller zeroes it.  xnrs_status_string explains a value.
+ *   XNRS_STATUS_NONBINARY_MASK  xnrs_text_encoder_fwd_compact met a mask value other than 0 / 1
+ *   XNRS_STATUS_ROW_RANGE       (set by the Python host layer, NewsStore.gather) a table row id outside the table; the
+ *                               id was clamped so that no kernel read out of bounds */
+#define XNRS_STATUS_NONBINARY_MASK 1
+#define XNRS_STATUS_ROW_RANGE 2
+int32_t xnrs_set_status_word(int32_t *device_word);
+const char *xnrs_status_string(int32_t word);
+
 /* ---- arithmetic mode of the forward GEMMs (nn.Linear call sites listed at xnrs_linear_fwd) ----------
  *   XNRS_GEMM_F32     (0, default) v_mfma_f32_32x32x2_f32: an exact fp32 fmaf chain.
  *   XNRS_GEMM_BF16X3  (1) each fp32 operand is split exactly into three bf16 pieces and the product is

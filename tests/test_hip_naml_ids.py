@@ -101,8 +101,15 @@ def test_naml_from_the_on_disk_store(tmp_path):
         x, m = dstore.gather(rows, feat)
         assert np.array_equal(x.cpu().numpy(), fx[rows.cpu().numpy()])
         assert np.array_equal(m.cpu().numpy()[..., 0], fm[rows.cpu().numpy()].astype(np.float32))
-    with pytest.raises(IndexError):
-        dstore.gather(torch.tensor([25], dtype=torch.int32, device=DEV))
+    with pytest.raises(IndexError):  # the blocking check (two host reads) on request ...
+        dstore.gather(torch.tensor([25], dtype=torch.int32, device=DEV), trusted=False)
+    # ... by default no host read: the id is clamped (no out-of-bounds access) and the sticky status word says so later
+    from xnrs_amd import hip
+    hip.check_status()
+    dstore.gather(torch.tensor([3, 25, -2], dtype=torch.int32, device=DEV))
+    with pytest.raises(hip.XnrsHipError, match="row id outside the table"):
+        hip.check_status()
+    hip.check_status()  # read and cleared
     model, _ = naml_model()
     check_sessions(model, dstore, store, sessions)
 

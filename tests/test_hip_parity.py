@@ -566,3 +566,33 @@ def test_device_compacted_encoder_and_graph_capture(tower):
             enc.unpadded = enc.skip_empty = False
         yd, hmd = ops.text_encoder(x2, m2, enc)
         assert torch.equal(yg.reshape(n, E), yd) and torch.equal(hmg.reshape(n), hmd)
+
+
+def test_nonbinary_mask_on_the_device_compacted_path_sets_the_status_word():
+    """The device-compacted encoder never synchronises, so a mask value other than 0 / 1 cannot raise from it: its outputs
+    are NaN AND the sticky device status word (include/xnrs_hip.h: xnrs_set_status_word) carries XNRS_STATUS_NONBINARY_MASK
+    until the caller reads it (hip.check_status()); ops.check_binary_mask is the set-up-time check that raises at once."""
+    from xnrs_amd import hip, ops
+    S, D, h, E = 20, 64, 4, 32
+    enc = news_encoding.TextEncoder(pooler=layers.AdditiveAttention(D, 64), p_dropout=0.0, out_features=E, in_features=D,
+                                    att=layers.MultiHeadAttention(h, D))
+    enc = enc.eval().to(DEV)
+    rng = synth.rng_for(9100)
+    x, m = synth.token_block(rng, 1, 40, S, D, min_len=2)
+    x, m = x.to(DEV), m.to(DEV)
+    enc.unpadded = True
+    hip.check_status()
+    with torch.no_grad():
+        y_ok, _ = enc((x, m))
+        assert torch.isfinite(y_ok).all()
+        hip.check_status()  # nothing to report
+        bad = m.clone()
+        bad[0, 3, 1, 0] = 0.5
+        with pytest.raises(ValueError):
+            ops.check_binary_mask(bad)
+        ops.check_binary_mask(m)
+        y_bad, _ = enc((x, bad))
+        assert torch.isnan(y_bad).all()
+    with pytest.raises(hip.XnrsHipError, match="mask value other than 0 / 1"):
+        hip.check_status()
+    hip.check_status()

@@ -105,11 +105,19 @@ def test_random_bi_encoder_matches_oracle(seed):
     H.assert_close(r3, ref, what=what + " bf16x3 scores")
 
 
-@pytest.mark.parametrize("seed", range(16))
+# seeds 200..231: the round-3 soak range (tools/soak_random_shapes.py), pinned in round 4 together with the bar below
+@pytest.mark.parametrize("seed", list(range(16)) + list(range(200, 232)))
 def test_random_bi_encoder_gradients_match_oracle(seed):
     """The hand-written backward (xnrs_seq_encoder_bwd and friends) against torch autograd of the CPU oracle on
     the same random configurations: parameter gradients of both towers and the input gradients d loss / d x that
-    the explainer needs (explain.py:160-166)."""
+    the explainer needs (explain.py:160-166).
+
+    `pooler.fc2.bias` of an additive pooler has its own bar.  Its gradient is sum_i de_i with de_i = a_i (da_i - sum_j a_j da_j):
+    per sequence that is (sum_i a_i da_i) (1 - sum_i a_i) = O(1e-8) -- the bias shifts every score of a sequence alike and only
+    the `+ 1e-8` of layers.py:64 keeps the weights from being invariant to it.  Both sides therefore compare two fp32 sums of
+    n = rows terms that cancel analytically; what is left on EITHER side is summation noise of order sqrt(n) * 2^-23 * |de|,
+    and |de| is bounded through its sibling gradient d fc2.weight = sum_i de_i tanh(.)_i.  Bar for this key: the usual
+    2e-4 of the scale PLUS 4 sqrt(n) 2^-23 max|d fc2.weight| (one round-3 soak seed sat at 2.1e-4 of the scale without it)."""
     c = _cfg(100 + seed)
     D, S, A, h = c["D"], min(c["S"], 64), c["A"], c["h"]
     Eo = c["E"] if c["head_news"] else D
@@ -160,6 +168,13 @@ def test_random_bi_encoder_gradients_match_oracle(seed):
         assert p.grad is not None, f"{what}: no grad for {k}"
         scale = max(ref.abs().max().item(), 1e-3 * gmax)
         e = (p.grad.cpu().double() - ref.double()).abs().max().item() / scale
-        assert e <= 2e-4, f"{what}: {k}: {e:.3e}"
+        bar = 2e-4
+        if k.endswith("pooler.fc2.bias"):
+            rows = (c["B"] * Hn * S) if k.startswith("news_encoder.") else c["B"] * Hn
+            if k.startswith("news_encoder."):
+                rows += c["B"] * c["C"] * S  # the candidates go through the same tower
+            gw = osd[k[:-len("bias")] + "weight"].grad.abs().max().item()
+            bar += 4.0 * (rows ** 0.5) * 2.0 ** -23 * gw / scale
+        assert e <= bar, f"{what}: {k}: {e:.3e} (bar {bar:.3e})"
         n += 1
     assert n >= 2

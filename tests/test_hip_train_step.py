@@ -282,3 +282,26 @@ def test_standardrec_second_encode_is_the_first_bit_for_bit(monkeypatch):
     model.get_user_embeddings(batch)
     assert AG.STATS["shared_output_forwards"] == before
     del r
+
+
+def test_shared_projection_is_bitwise_neutral_with_attention_dropout_on(monkeypatch):
+    """The shipped train mode (attention dropout 0.1): the second history encode reading the first one's Q|K|V image
+    (autograd._QKV_IMAGES) gives bit for bit the loss and gradients of the step that projects twice -- the two encodes draw
+    different dropout masks, their projections are the same numbers.  (Merged weight gradients off: they change the
+    summation order and have their own test above.)"""
+    from xnrs_amd import autograd as AG
+    c = dict(model="NRMS", B=8, H=12, C=3, S=50, D=64, h=4, E=32, bias=False, seed=4606, min_len=3)
+    monkeypatch.setattr(AG, "LIVE_ROWS_MIN", 1)
+    monkeypatch.setattr(AG, "MERGE_DW", False)
+    model = _nrms(c, 0.1)
+    batch = synth.batch_to(cases.model_batch(c), DEV)
+    labels = torch.tensor([0, 1, 0, 2, 1, 0, 2, 2], device=DEV)
+    monkeypatch.setattr(AG, "SHARE_QKV", False)
+    l0, g0 = _step(model, batch, labels)
+    monkeypatch.setattr(AG, "SHARE_QKV", True)
+    before = AG.STATS["shared_qkv_forwards"]
+    l1, g1 = _step(model, batch, labels)
+    assert AG.STATS["shared_qkv_forwards"] == before + 1
+    assert torch.equal(l0, l1) and g0.keys() == g1.keys()
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k

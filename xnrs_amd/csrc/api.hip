@@ -638,6 +638,20 @@ int32_t xnrs_abi_version(void) { return XNRS_ABI_VERSION; }
 #endif
 const char* xnrs_build_id(void) { return XNRS_BUILD_ID; }
 
+int32_t xnrs_set_status_word(int32_t* device_word) {
+  set_status_word(device_word);
+  return XNRS_OK;
+}
+
+const char* xnrs_status_string(int32_t word) {
+  switch (word & 3) {
+    case 0: return "ok";
+    case XNRS_STATUS_NONBINARY_MASK: return "a mask value other than 0 / 1 reached the device-compacted encoder (its outputs are NaN)";
+    case XNRS_STATUS_ROW_RANGE: return "a news-table row id outside the table (clamped; the gathered rows are wrong)";
+    default: return "a mask value other than 0 / 1 reached the device-compacted encoder AND a table row id was out of range";
+  }
+}
+
 size_t xnrs_row_lists_workspace_bytes(int64_t n_seq) { return n_seq > 0 ? align_up((size_t)n_seq * sizeof(int32_t)) : 0; }
 
 int32_t xnrs_build_row_lists(const float* m, const int32_t* ids, int64_t n_seq, int32_t L, int32_t* live_rows,

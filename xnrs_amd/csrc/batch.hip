@@ -13,6 +13,8 @@
 //                    device copy: out[i] = table[ids[i]] for whole news blocks (S*D floats, 150 KB at the shipped
 //                    shape) -- the materialised batch for consumers that need dense token tensors (input gradients
 //                    of the explainer, explain.py:160-166); the encoders themselves gather inside their first load.
+#include <atomic>
+
 #include "kernels.h"
 
 namespace xnrs {
@@ -557,10 +559,12 @@ hipError_t launch_build_row_lists(const float* mask, const int32_t* ids, int64_t
 }
 
 // NaN over a result whose precondition turned out violated on the device (the flags of every pass, OR-ed)
-__global__ __launch_bounds__(256) void poison_kernel(float* y, int64_t n, const int64_t* flags, int n_flags, int flag_stride) {
+__global__ __launch_bounds__(256) void poison_kernel(float* y, int64_t n, const int64_t* flags, int n_flags, int flag_stride,
+                                                     int32_t* status) {
   bool bad = false;
   for (int i = 0; i < n_flags; ++i) bad = bad || flags[(int64_t)i * flag_stride] != 0;
   if (!bad) return;
+  if (status && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(status, 1 /* XNRS_STATUS_NONBINARY_MASK */);
   const float nanv = __builtin_nanf("");
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = nanv;
 }
@@ -569,9 +573,13 @@ hipError_t launch_poison(float* y, int64_t n, const int64_t* flags, int n_flags,
   if (n <= 0 || n_flags <= 0) return hipSuccess;
   int64_t blocks = (n + 255) / 256;
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(poison_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, y, n, flags, n_flags, flag_stride);
+  hipLaunchKernelGGL(poison_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, y, n, flags, n_flags, flag_stride, status_word());
   return hipGetLastError();
 }
+
+static std::atomic<int32_t*> g_status_word{nullptr};
+int32_t* status_word() { return g_status_word.load(std::memory_order_relaxed); }
+void set_status_word(int32_t* w) { g_status_word.store(w, std::memory_order_relaxed); }
 
 hipError_t launch_compact_rows(const float* mask, const int32_t* ids, int64_t n_news, int64_t chunk, int S, int64_t* row_off,
                                int32_t* live_src, int32_t* kv_src, int32_t* kv_block, int64_t* counts, hipStream_t stream) {

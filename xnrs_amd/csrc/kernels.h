@@ -505,6 +505,10 @@ struct BatchArgs {
 hipError_t launch_gather_rows(const float* table, const int32_t* ids, float* out, int64_t n, int64_t row_floats,
                               hipStream_t stream);
 hipError_t launch_poison(float* y, int64_t n, const int64_t* flags, int n_flags, int flag_stride, hipStream_t stream);
+// the caller's sticky device status word (xnrs_set_status_word; nullptr = none): kernels OR XNRS_STATUS_* bits into it when
+// they meet a violated precondition that no host code could check without a synchronisation
+int32_t* status_word();
+void set_status_word(int32_t* w);
 // live-row / kept-K|V-row lists + CSR offsets of every pass of `chunk` news, built on the device in one launch (batch.hip):
 // pass p writes row_off[p*(chunk+1) ..], the lists at [p*chunk*S ..], kv_block[p*chunk ..], counts[3*p ..]
 hipError_t launch_compact_rows(const float* mask, const int32_t* ids, int64_t n_news, int64_t chunk, int S, int64_t* row_off,

@@ -108,13 +108,33 @@ class NewsStore:
                 raise IndexError(f"NewsStore: {what} out of range [{lo}, {hi}] for a table of {self.n_rows} rows")
         return flat
 
-    def gather(self, rows: torch.Tensor, feature: Optional[str] = None, trusted: bool = False):
+    def validate_masks(self) -> None:
+        """Every mask of the store is 0 / 1 (one host sync per feature: set-up, not the step) -- what the padding-free
+        encoders require and the device-compacted one cannot check without a sync (ops.check_binary_mask)."""
+        from . import ops
+        for name in [self.feature] + sorted(self.texts):
+            ops.check_binary_mask(self.text(name)[1], f"NewsStore mask of '{name}'")
+
+    def gather(self, rows: torch.Tensor, feature: Optional[str] = None, trusted: Optional[bool] = None):
         """Dense (x:(*rows.shape,S,D), m:(*rows.shape,S,1)) for int32 table rows -- the tensors the reference's dataset
         would have built on the host (dataset.py:63-85,97-109).  Only for consumers that need the batch itself (input
-        gradients of the explainer); the encoders take the rows directly (forward_ids)."""
+        gradients of the explainer); the encoders take the rows directly (forward_ids).
+
+        Row ids are range-checked WITHOUT a host read by default (trusted=None): ids are clamped into the table, so the
+        kernel never reads out of bounds, and an id that had to be clamped sets hip.STATUS_ROW_RANGE in the sticky device
+        status word -- hip.check_status() raises at the caller's next sync point.  trusted=False: the old blocking check
+        (two .item() reads, IndexError at once); trusted=True: no check at all."""
         tx, tm = self.text(feature or self.feature)
         tx, tm = hip.dev_f32(tx, "news table"), hip.dev_f32(tm, "news table mask")
-        flat = rows.reshape(-1).to(torch.int32).contiguous() if trusted else self.check_rows(rows)
+        if trusted is False:
+            flat = self.check_rows(rows)
+        else:
+            flat = rows.reshape(-1).to(torch.int32).contiguous()
+            if trusted is None and flat.is_cuda and flat.numel():
+                ok = flat.clamp(0, self.n_rows - 1)
+                bad = (ok != flat).any().to(torch.int32) * hip.STATUS_ROW_RANGE
+                hip.status_word(flat.device).bitwise_or_(bad.reshape(1))
+                flat = ok
         if not flat.is_cuda:
             raise hip.XnrsHipError("NewsStore.gather: the rows must live on the HIP device")
         n, (S, D) = flat.numel(), tx.shape[1:]

@@ -162,7 +162,12 @@ class GradBucket:
     """One persistent flat fp32 buffer that every parameter's `.grad` is a VIEW of: the backward accumulates straight
     into it, `allreduce()` is one in-place SUM all-reduce over it (a single bucket: the whole model is <= 12.6 MB, so the
     collective is latency-bound and bucketing would only add launches), and nothing is concatenated or copied back.
-    Use `bucket.zero_grad()` instead of `optimizer.zero_grad()` (which would drop the views with set_to_none=True)."""
+    Use `bucket.zero_grad()` instead of `optimizer.zero_grad()` (which would drop the views with set_to_none=True).
+
+    One difference from the reference's `optimizer.zero_grad()` (set_to_none): EVERY parameter that requires grad holds a
+    gradient view here, so a parameter the step never touches (dummy_param) carries zeros where the reference leaves None.
+    Adam then keeps (zero) state for it and steps it by 0; an optimizer with weight decay WOULD decay it.  None of the
+    shipped configs uses weight decay; pass only the parameters that take part in the step if yours does."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]

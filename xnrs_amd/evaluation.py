@@ -123,4 +123,6 @@ def evaluate(model, store: NewsStore, behaviors: Behaviors, l_hist: int, batch: 
         r = score_csr(vecs, rows, csess, u, relu=True)
         sums += rank_metrics(r, targets, off).double().sum(0)
     mean = sharded_mean(sums, n, on)
-    return {k: float(v) for k, v in zip(METRIC_NAMES, mean.tolist())}
+    out = {k: float(v) for k, v in zip(METRIC_NAMES, mean.tolist())}
+    hip.check_status(dev)  # (the read above was the epoch's sync point: what the sync-free encoders could not raise, raises here)
+    return out

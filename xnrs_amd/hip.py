@@ -36,7 +36,7 @@ SYMBOLS = (
     "xnrs_fold_weights_workspace_bytes", "xnrs_fold_weights",
     "xnrs_text_encoder_compact_workspace_bytes", "xnrs_text_encoder_fwd_compact",
     "xnrs_seq_encoder_fwd_train_rows", "xnrs_seq_encoder_bwd_rows", "xnrs_seq_encoder_saved_qkv_offset",
-    "xnrs_build_id", "xnrs_row_lists_workspace_bytes", "xnrs_build_row_lists",
+    "xnrs_build_id", "xnrs_row_lists_workspace_bytes", "xnrs_build_row_lists", "xnrs_set_status_word", "xnrs_status_string",
 )
 POOL_NONE = -1
 PROFILE_STAGES = ("qkv_gemm", "attention_core", "out_gemm", "fc1_tanh_gemm", "pool", "head_gemms", "news_fused",
@@ -215,10 +215,43 @@ def lib():
     l.xnrs_row_lists_workspace_bytes.argtypes = [i64]
     l.xnrs_build_row_lists.restype = i32
     l.xnrs_build_row_lists.argtypes = [p, p, i64, i32, p, p, p, p, p, p, sz, p]
+    l.xnrs_set_status_word.restype = i32
+    l.xnrs_set_status_word.argtypes = [p]
+    l.xnrs_status_string.restype = C.c_char_p
+    l.xnrs_status_string.argtypes = [i32]
     if l.xnrs_abi_version() != 6:
         raise XnrsHipError("libxnrs_hip.so ABI version mismatch; rebuild it")
     _lib = l
     return l
+
+
+# ---- sticky device status word (include/xnrs_hip.h): what the sync-free entry points could not raise
+STATUS_NONBINARY_MASK, STATUS_ROW_RANGE = 1, 2
+_status = {}
+
+
+def status_word(device) -> torch.Tensor:
+    """The int32 device word the library's sync-free paths OR their error bits into (one per process: registered with the
+    library on first use; xnrs_amd runs one device per process).  Read it with check_status() at a natural sync point."""
+    dev = torch.device(device)
+    w = _status.get(dev.index)
+    if w is None:
+        w = torch.zeros(1, dtype=torch.int32, device=dev)
+        _status[dev.index] = w
+        check(lib().xnrs_set_status_word(C.c_void_p(w.data_ptr())), "xnrs_set_status_word")
+    return w
+
+
+def check_status(device=None):
+    """Read (one host sync) and clear the status word(s); raise XnrsHipError for what a sync-free call could not report:
+    a non-binary mask in the device-compacted encoder (its outputs are NaN), a table row id outside the table."""
+    for idx, w in list(_status.items()):
+        if device is not None and torch.device(device).index != idx:
+            continue
+        v = int(w.item())
+        if v:
+            w.zero_()
+            raise XnrsHipError(f"device status word {v}: {lib().xnrs_status_string(v).decode()}")
 
 
 def build_id() -> str:

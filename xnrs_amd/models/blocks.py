@@ -101,6 +101,11 @@ class TextEncoder(_Tower):
     # Opt-in (inference, additive pooler, 0/1 masks): additionally skip the masked TOKEN rows wherever they cannot
     # reach the output (query projection, attention rows, output projection, fc1, pooling); K and V are still
     # projected for every token because the reference masks query rows only (ops.text_encoder_forward_unpadded).
+    # Masks must be binary.  On supported shapes this runs the DEVICE-compacted entry point, which never synchronises and so
+    # cannot raise for a fractional mask: its outputs are NaN and hip.STATUS_NONBINARY_MASK is set in the sticky status
+    # word (hip.check_status() at the caller's next sync point raises); the host-compacted path (other shapes,
+    # XNRS_COMPACT_ON_DEVICE=0) raises ValueError per call, the dense path computes exp(e)*m like the reference.  Validate a
+    # dataset once with ops.check_binary_mask / NewsStore.validate_masks().
     unpadded: bool = False
 
     def _encoder_fn(self):

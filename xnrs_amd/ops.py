@@ -248,8 +248,18 @@ def text_encoder_forward_compact(x: torch.Tensor, m: torch.Tensor, att, pooler, 
     A, E = pp.hidden, (hp.out_features if hp is not None else D)
     y = torch.empty((n, E), dtype=torch.float32, device=x.device)
     hm = torch.empty((n,), dtype=torch.float32, device=x.device)
+    hip.status_word(x.device)  # (registered once: a non-binary mask sets STATUS_NONBINARY_MASK there; hip.check_status())
     l = hip.lib()
     nbytes = l.xnrs_text_encoder_compact_workspace_bytes(n, S, D, A, E, int(att is not None), int(head is not None), chunk)
+    # The default pass (262 144 / S news) needs ~3.2 GB of worst-case scratch at D = 768, and hip.workspace is grow-only per
+    # stream: bound it (XNRS_COMPACT_WS_MB, default 4096) by shrinking the pass -- the scratch scales with the news per pass
+    cap = int(os.environ.get("XNRS_COMPACT_WS_MB", "4096")) << 20
+    if chunk == 0 and nbytes > cap:
+        per_pass = max(262144 // max(S, 1), 1)
+        while nbytes > cap and per_pass > 64:
+            per_pass //= 2
+            nbytes = l.xnrs_text_encoder_compact_workspace_bytes(n, S, D, A, E, int(att is not None), int(head is not None), per_pass)
+        chunk = per_pass
     ws = hip.workspace(x.device, nbytes)
     hip.check(l.xnrs_text_encoder_fwd_compact(hip.ptr(x), hip.ptr(m2), hip.ptr(ids), n, S, D, None if ap is None else C.byref(ap),
                                               C.byref(pp), None if hp is None else C.byref(hp), hip.ptr(y), hip.ptr(hm), chunk,
@@ -412,9 +422,24 @@ def text_encoder_unpadded(x, m, enc, ids=None):
         return text_encoder(x, m, enc, ids=ids)
     if COMPACT_ON_DEVICE and compact_supported(S, D, att, pooler):
         # row lists built on the device: no host sync, capturable; all-masked news cost nothing (so skip_empty's host-side
-        # compaction is not needed on top)
-        return text_encoder_forward_compact(x, m, att, pooler, head, ids=ids)
+        # compaction is not needed on top).  A device without room for its scratch falls back to the host-compacted path
+        # (the same results) instead of failing: hip.release_workspaces() returns the scratch when eval and train alternate
+        try:
+            return text_encoder_forward_compact(x, m, att, pooler, head, ids=ids)
+        except torch.OutOfMemoryError:
+            hip.release_workspaces()
     return text_encoder_forward_unpadded(x, m, att, pooler, head, ids=ids)
+
+
+def check_binary_mask(m: torch.Tensor, what: str = "mask") -> None:
+    """Raise ValueError unless every mask value is 0 or 1 (ONE host sync: set-up code, never the step).  The padding-free
+    paths require binary masks (an unmasked row is simply "live"); the host-compacted path checks this per call, the
+    device-compacted one (TextEncoder.unpadded on supported shapes) cannot raise from the device -- it writes NaN outputs
+    and sets hip.STATUS_NONBINARY_MASK in the sticky status word (hip.check_status()).  Call this once per dataset instead
+    (NewsStore.validate_masks)."""
+    bad = ((m != 0) & (m != 1)).any()
+    if bool(bad.item()):
+        raise ValueError(f"{what}: values other than 0 / 1 (the reference's masks are fp32 0/1, news_encoding.py:34-50)")
 
 
 #: TextEncoder.unpadded compacts on the device when the shape allows (XNRS_COMPACT_ON_DEVICE=0: always the host-compacted path)
