@@ -10,7 +10,7 @@ import torch
 from oracle import xnrs_oracle as O
 from tests import helpers as H
 from tests.golden import cases
-from xnrs_amd import synth
+from xnrs_amd import hip, synth
 from xnrs_amd.models import make_model
 from xnrs_amd.models.components import layers, news_encoding, user_encoding, scoring
 
@@ -380,6 +380,8 @@ def test_unpadded_encoder_matches_padded(tower):
         if ops.compact_supported(S, D, enc.att, enc.pooler):  # (not under XNRS_FOLD_OUT=0 / the split GEMM modes)
             yb, hmb = ops.text_encoder_forward_compact(x, m * 0.5, enc.att, enc.pooler, enc.head)
             assert torch.isnan(yb).all() and torch.isnan(hmb).all()
+            with pytest.raises(hip.XnrsHipError, match="mask value other than 0 / 1"):
+                hip.check_status()  # ... and says so in the sticky status word (read and cleared here)
 
 
 def test_naml_with_padding_free_encoders_matches_golden():
@@ -581,7 +583,7 @@ def test_nonbinary_mask_on_the_device_compacted_path_sets_the_status_word():
     x, m = synth.token_block(rng, 1, 40, S, D, min_len=2)
     x, m = x.to(DEV), m.to(DEV)
     enc.unpadded = True
-    hip.check_status()
+    hip.clear_status()  # (sticky by design: an earlier test may have left its bit)
     with torch.no_grad():
         y_ok, _ = enc((x, m))
         assert torch.isfinite(y_ok).all()

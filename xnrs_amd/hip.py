@@ -254,6 +254,12 @@ def check_status(device=None):
             raise XnrsHipError(f"device status word {v}: {lib().xnrs_status_string(v).decode()}")
 
 
+def clear_status():
+    """Zero the status word(s) without reading them (no sync)."""
+    for w in _status.values():
+        w.zero_()
+
+
 def build_id() -> str:
     """Hash of the sources libxnrs_hip.so was built from (include/xnrs_hip.h: xnrs_build_id)."""
     return lib().xnrs_build_id().decode()
