@@ -899,7 +899,10 @@ def train_scaling(args, device, rank, world, dist_on):
     # persistent gradient bucket
     def factory(model):
         D.broadcast_parameters(model)
-        return (D, D.ShardLayout.uniform(w["B"]), D.GradBucket(model.parameters()), n_global)
+        # --overlap-buckets: one bucket per tower, all-reduced asynchronously as each completes during the backward
+        # (xnrs_amd.distributed.OverlappedGradBuckets); default: ONE flat bucket reduced after the backward
+        bucket = D.OverlappedGradBuckets.by_tower(model) if args.overlap_buckets else D.GradBucket(model.parameters())
+        return (D, D.ShardLayout.uniform(w["B"]), bucket, n_global)
     model, opt, batch, targets, labels, fn = make_train_job(args.train, device, seed=2000 + rank,
                                                             dist_factory=factory if dist_on else None, stub=stub)
     dt = timed(fn, args.steps, args.warmup, dist_on, device=device)
@@ -915,8 +918,9 @@ def train_scaling(args, device, rank, world, dist_on):
                                    "two history encodes, training.py:402-431), 64 impressions per GPU (H=25, C=5, S=50, D=768), global "
                                    "in-batch InfoNCE (lambda 0.1, tau 0.08), train mode (NRMS: attention dropout 0.1)",
                        "parallelism": f"impressions sharded over {n_gpus} GPU(s); per step ONE all-gather of (64, 256+1) [user "
-                                      "embedding | label bits] + ONE flat fp32 gradient all-reduce in a persistent bucket, no "
-                                      "host sync"},
+                                      "embedding | label bits] + " + ("one asynchronous fp32 gradient all-reduce per tower, overlapped "
+                                      "with the backward" if args.overlap_buckets else "ONE flat fp32 gradient all-reduce in a "
+                                      "persistent bucket") + ", no host sync"},
             "loss_finite": bool(torch.isfinite(fn()).item())}
 
 
@@ -934,6 +938,9 @@ def main():
                     help="time the data-parallel GRAD step instead (BASELINE configs[3]: impressions sharded over the "
                          "ranks, global in-batch InfoNCE through a differentiable all-gather, one flat RCCL gradient "
                          "all-reduce); prints its own JSON line")
+    ap.add_argument("--overlap-buckets", action="store_true",
+                    help="with --train: one gradient bucket per tower, all-reduced asynchronously as each completes during the "
+                         "backward (default: one flat bucket after the backward)")
     ap.add_argument("--selftest-backend", choices=("gloo",), default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus < 1:

@@ -71,3 +71,8 @@ def test_train_line_launcher_path_over_gloo():
     assert out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak" and out["loss_finite"] is True
     assert out["unit"] == "impressions/s" and out["value"] > 0 and out["ms_per_step"] > 0
     assert "two history encodes" in out["config"]["workload"] and "all-reduce" in out["config"]["parallelism"]
+    # ... and with one asynchronous bucket per tower
+    p = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--train", "nrms", "--overlap-buckets", "--selftest-backend", "gloo"])
+    assert p.returncode == 0, p.stderr
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["loss_finite"] is True and "per tower" in out["config"]["parallelism"]

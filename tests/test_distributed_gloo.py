@@ -72,7 +72,7 @@ class _Count:
         return sum(self.n.values())
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, overlapped=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -90,8 +90,15 @@ def _worker(rank, world, port, out):
     layout = D.ShardLayout.exchange(hi - lo)
     assert layout.sizes == [b - a for a, b in (D.shard_range(C["B"], r, world) for r in range(world))]
     assert layout.equal == (C["B"] % world == 0)
-    bucket = D.GradBucket(sd.values())
-    # ---- the step: exactly two collectives, no host read
+    if overlapped:  # two buckets in the order their gradients complete: [user tower, news tower], reduced as they complete
+        user = [v for k, v in sd.items() if not k.startswith("news_encoder.")]
+        news = [v for k, v in sd.items() if k.startswith("news_encoder.")]
+        bucket = D.OverlappedGradBuckets([user, news])
+        assert len(bucket.buckets) == 2
+    else:
+        bucket = D.GradBucket(sd.values())
+    n_reduce = 2 if overlapped else 1
+    # ---- the step: exactly two collectives (three with the two overlapped buckets), no host read
     for _ in range(2):  # twice: the second pass shows the bucket's views survive a step (gradients do not accumulate)
         with _Count() as cnt:
             bucket.zero_grad()
@@ -103,10 +110,13 @@ def _worker(rank, world, port, out):
             loss = D.global_train_loss(loss_rec, hi - lo, C["B"], loss_cl, C["lambda_cl"])
             loss.backward()
             bucket.allreduce()
-        assert cnt.total == 2 and cnt.n["all_gather_into_tensor"] == 1 and cnt.n["all_reduce"] == 1, cnt.n
+        assert cnt.total == 1 + n_reduce and cnt.n["all_gather_into_tensor"] == 1 and cnt.n["all_reduce"] == n_reduce, cnt.n
         assert cnt.syncs == 0, f"{cnt.syncs} host reads inside the step"
         assert torch.equal(lab_all, labels_full) and lab_all.dtype == labels_full.dtype
-        assert all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in bucket.params)
+        for b in (bucket.buckets if overlapped else [bucket]):
+            assert all(p.grad.data_ptr() >= b.flat.data_ptr() for p in b.params)
+        if overlapped:  # the user tower's bucket completed by its hooks DURING the backward (before finish() was called)
+            assert bucket._launched == [True, True]
     # the convenience forms (sizes exchanged inside) agree with the fused gather
     assert torch.equal(D.all_gather_rows(ue.detach()), ue_all.detach())
     assert torch.equal(D.all_gather_labels(labels_full[lo:hi]), labels_full)
@@ -121,13 +131,15 @@ def _worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(180)
-@pytest.mark.parametrize("world", [2, 4])  # 6 impressions: 3+3 (equal shards) and 2+2+1+1 (ragged last shards)
-def test_n_rank_train_step_equals_single_process(world):
+@pytest.mark.parametrize("world,overlapped", [(2, False), (4, False), (2, True)])  # 6 impressions: 3+3 (equal shards) and 2+2+1+1 (ragged)
+def test_n_rank_train_step_equals_single_process(world, overlapped):
+    """overlapped: xnrs_amd.distributed.OverlappedGradBuckets -- one bucket per tower, all-reduced asynchronously as soon as
+    the tower's last gradient has been accumulated (post-accumulate hooks), the rest of the backward running meanwhile."""
     loss1, g1 = _single()
     mgr = mp.Manager()
     out = mgr.dict()
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, out, overlapped), nprocs=world, join=True)
     assert abs(out["loss"].item() - loss1.item()) <= 1e-6 * max(1.0, abs(loss1.item()))
     gmax = max(v.abs().max().item() for v in g1.values())
     for k, ref in g1.items():

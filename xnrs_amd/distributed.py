@@ -212,6 +212,85 @@ class GradBucket:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
 
 
+class OverlappedGradBuckets:
+    """Several GradBuckets reduced AS THEY COMPLETE during the backward, on a side stream, overlapped with the rest of the
+    backward (round 4; the single GradBucket reduces after the backward has finished).
+
+    The gradients of a tower are complete when its last autograd node has run: in the grad step of the bi-encoders the
+    user tower finishes first and the news tower (whose last node computes the Q|K|V weight gradients, the largest products
+    of the step) last.  `groups` lists the parameters per bucket in that order -- `by_tower(model)` builds
+    [user tower | scorer, news tower] for the ParentRec / NAML models.  Every parameter gets a post-accumulate hook; when
+    the last parameter of a bucket has received its gradient the bucket's flat buffer is all-reduced asynchronously
+    (communication stream; the compute stream waits for it only in `finish()`).  Buckets that never complete by hooks
+    (a parameter without a gradient in this step, e.g. dummy_param) are reduced in `finish()`, so correctness never
+    depends on the hooks: n_buckets collectives per step, always.
+
+    Use: `buckets.zero_grad()`; forward; `loss.backward()`; `buckets.finish()`; `optimizer.step()`."""
+
+    def __init__(self, groups):
+        self.buckets = [GradBucket(g) for g in groups if any(p.requires_grad for p in g)]
+        self._pending = []
+        self._left = []
+        self._work = []
+        self._hooks = []
+        for bi, b in enumerate(self.buckets):
+            for p in b.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, _bi=bi: self._arrived(_bi)))
+        self._reset()
+
+    @classmethod
+    def by_tower(cls, model: torch.nn.Module):
+        """[everything that is not the news tower, the news tower]: the order in which their gradients complete."""
+        news, rest = [], []
+        for name, p in model.named_parameters():
+            if not p.requires_grad:
+                continue
+            (news if name.startswith(("news_encoder.", "title_encoder.", "body_encoder.", "cat_", "subcat_", "feature_pooler."))
+             else rest).append(p)
+        return cls([g for g in (rest, news) if g])
+
+    def _reset(self):
+        self._left = [len(b.params) for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._work = []
+
+    def zero_grad(self):
+        for b in self.buckets:
+            b.zero_grad()
+        self._reset()
+
+    def _launch(self, bi):
+        b = self.buckets[bi]
+        self._launched[bi] = True
+        if not b.flat.numel():
+            return
+        if not b._attached():
+            b.allreduce()  # (a gradient was re-allocated behind the bucket's back: the synchronous, repairing path)
+            return
+        self._work.append(dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, async_op=True))
+
+    def _arrived(self, bi):
+        self._left[bi] -= 1
+        if self._left[bi] == 0 and not self._launched[bi]:
+            self._launch(bi)
+
+    def finish(self):
+        """After loss.backward(): reduce what the hooks did not, then make the current stream wait for every reduction."""
+        for bi in range(len(self.buckets)):
+            if not self._launched[bi]:
+                self._launch(bi)
+        for w in self._work:
+            w.wait()
+        self._work = []
+
+    allreduce = finish  # drop-in for GradBucket in a step that calls bucket.allreduce()
+
+    def remove_hooks(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
 def allreduce_gradients(params: Iterable[torch.nn.Parameter]) -> None:
     """One-off flat SUM all-reduce (concatenates and copies back: tests and set-up code; the training loop keeps a
     GradBucket instead)."""
