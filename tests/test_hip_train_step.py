@@ -305,3 +305,4 @@ def test_shared_projection_is_bitwise_neutral_with_attention_dropout_on(monkeypa
     assert torch.equal(l0, l1) and g0.keys() == g1.keys()
     for k in g0:
         assert torch.equal(g0[k], g1[k]), k
+

@@ -30,7 +30,8 @@ print(f"forward, device-compacted: {N} steps, {bad} differ from the dense first 
 
 w2 = dict(B=64, H=25, C=5, S=50, D=768, h=16, E=256, A=256)
 m2, _ = bench.build_model(w2, dev)
-m2.eval()  # no dropout: identical steps
+m2.train()  # attention dropout 0.1 ON, the same seeds every step (torch.manual_seed below): identical steps through the
+            # shared projection AND the merged weight-gradient products (eval mode would share the second encode whole)
 h2, c2 = bench.make_inputs(w2, dev, seed=7)
 batch = {"user_features": {"history": {"title_emb": h2}, "other": {}}, "candidate_features": {"title_emb": c2}}
 tgt = torch.zeros(64, 5, 1, device=dev)
@@ -41,6 +42,7 @@ def grads():
     # the reference's step: scores, then the user embeddings of a second history encode (which reads the first one's Q|K|V
     # image, autograd._QKV_IMAGES) feeding a second loss term
     m2.zero_grad(set_to_none=True)
+    torch.manual_seed(5)
     loss = torch.nn.functional.mse_loss(torch.relu(m2(batch)), tgt)
     loss = loss + 0.1 * m2.get_user_embeddings(batch).square().mean()
     loss.backward()

@@ -372,6 +372,9 @@ def _device_lists(l, cfg, m, ids, dev):
 SHARE_OUTPUTS = os.environ.get("XNRS_SHARE_OUTPUTS", "1") != "0"
 _OUTPUTS = {}
 _OUTPUTS_HORIZON = 16  # encoder calls after which an unclaimed entry is dropped (a step's second encode follows within ~8)
+#: ... and a cap on the saved activations the unclaimed entries may pin (an entry keeps its graph, i.e. its saved blob, alive
+#: until its backward runs or it is dropped): a forward-only loop that forgot torch.no_grad() must not hoard a blob per call
+_OUTPUTS_MAX_BYTES = int(os.environ.get("XNRS_SHARE_OUTPUTS_MB", "4096")) << 20
 _TICK = 0
 
 
@@ -421,7 +424,7 @@ def _run(x, m, ids, att, pooler, head, pool_kind, dropout_p, seed, want_a):
                 _ident(ids), tuple(_ident(p) for p in params))
         hit = _OUTPUTS.get(okey)
         if hit is not None:
-            _, refs, (y, a, hm), ver = hit
+            _, refs, (y, a, hm), ver, _nb = hit
             if _alive(refs, objs) and y._version == ver and y.grad_fn is not None:
                 STATS["shared_output_forwards"] += 1
                 hit[0] = _TICK
@@ -434,8 +437,14 @@ def _run(x, m, ids, att, pooler, head, pool_kind, dropout_p, seed, want_a):
         # the entry holds the outputs themselves (modules drop them: a view of y fed to torch.cat keeps nothing alive) and
         # is dropped by the node's backward, or after _OUTPUTS_HORIZON further encoder calls
         wr = lambda t: None if t is None else weakref.ref(t)  # noqa: E731
-        _OUTPUTS[okey] = [_TICK, [wr(_root(o)) for o in objs], (y, a, hm), y._version]
+        _OUTPUTS[okey] = [_TICK, [wr(_root(o)) for o in objs], (y, a, hm), y._version, int(getattr(y.grad_fn, "nsaved", 0))]
         y.grad_fn.okey = okey
+        pinned = sum(v[4] for v in _OUTPUTS.values())
+        for k in sorted(_OUTPUTS, key=lambda k: _OUTPUTS[k][0]):  # oldest first; the entry just made always stays
+            if pinned <= _OUTPUTS_MAX_BYTES or k == okey:
+                break
+            pinned -= _OUTPUTS[k][4]
+            del _OUTPUTS[k]
     return y, a, hm
 
 

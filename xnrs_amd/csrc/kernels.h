@@ -321,21 +321,34 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return v;
 }
 
-// counter-based RNG for attention dropout (training mode only): splitmix64 finaliser on
-// (seed, element index) -> uniform [0,1).  Parity with torch's CPU Philox stream is impossible
-// (SURVEY.md section 7 "hard parts"); only the distribution matters.  Forward and backward call this with
-// the same (seed, index) so the mask is recomputed, never stored.
+// Counter-based RNG for attention dropout (training mode only) -> uniform [0,1) per probability.  Parity with torch's CPU
+// Philox stream is impossible (SURVEY.md section 7 "hard parts"); only the distribution matters (tests: expectation,
+// determinism per seed, forward / backward mask consistency).
 // the dropout seed of a launch: the host value plus, when given, a device word (wave-uniform scalar load)
 template <class Args>
 __device__ __forceinline__ uint64_t drop_seed(const Args& a) {
   return a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
 }
-__device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+// The dropout draw of probability (sequence, head, query, key): ONE splitmix64 of (seed, sequence * heads + head) -- invariant
+// in every loop that calls this, so the compiler computes it once per wave -- and per probability a 32-bit finaliser (murmur3
+// fmix32, a bijection) of its low word and the element's index inside the pair (query * S + key < 2^32), xor its high word.
+// Round 4: the first version ran splitmix64 on a 64-bit element index per probability (two 64-bit multiplies + the 64-bit
+// index arithmetic: ~0.2 ms of the 8.4 ms NRMS grad step, tools/bench_dropout_cost.py).  Forward and backward call this
+// with the same arguments, so the mask is recomputed, never stored.
+template <class Args>
+__device__ __forceinline__ float drop_uniform(const Args& a, int64_t seq, int hd, int S, int query, int key) {
+  uint64_t z = drop_seed(a) + 0x9E3779B97F4A7C15ull * ((uint64_t)(seq * a.n_heads + hd) + 1);
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   z = z ^ (z >> 31);
-  return (float)(z >> 40) * (1.0f / 16777216.0f);
+  uint32_t x = (uint32_t)z ^ ((uint32_t)(query * S + key) * 0x9E3779B9u);
+  x ^= x >> 16;
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  x ^= (uint32_t)(z >> 32);
+  return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
 
 // ---------------------------------------------------------------- fused news encoder, S <= 32 tokens (news_fused.hip)

@@ -144,8 +144,7 @@ __global__ __launch_bounds__(256) void mha_dq_kernel(MhaBwdArgs a, int QT, int64
         const float p = attn_exp(sv - mx) * inv_sum;
         float dpv = dp[kt][r];
         if (a.dropout_p > 0.f) {
-          const uint64_t idx = ((uint64_t)(seq * a.n_heads + hd) * S + (uint64_t)query) * S + (uint64_t)key;
-          dpv = (uniform01(drop_seed(a), idx) < keep) ? dpv / keep : 0.f;
+          dpv = (drop_uniform(a, seq, hd, S, query, key) < keep) ? dpv / keep : 0.f;
         }
         ds = p * (dpv - delta) * inv_sq;
       }
@@ -242,8 +241,7 @@ __global__ __launch_bounds__(256) void mha_dkdv_kernel(MhaBwdArgs a, int KTn, in
         float dpv = dp[r];
         pdv = p;
         if (a.dropout_p > 0.f) {
-          const uint64_t idx = ((uint64_t)(seq * a.n_heads + hd) * S + (uint64_t)query) * S + (uint64_t)key;
-          const bool kp = uniform01(drop_seed(a), idx) < keep;
+          const bool kp = drop_uniform(a, seq, hd, S, query, key) < keep;
           pdv = kp ? p / keep : 0.f;
           dpv = kp ? dpv / keep : 0.f;
         }
@@ -448,8 +446,7 @@ __global__ __launch_bounds__(256) void mha_bwd_fused_kernel(MhaBwdArgs a) {
           float dpv = dp[r];
           pdv = p;
           if (a.dropout_p > 0.f) {
-            const uint64_t idx = ((uint64_t)(seq * a.n_heads + hd) * S + (uint64_t)query) * S + (uint64_t)key;
-            const bool kp = uniform01(drop_seed(a), idx) < keep;
+            const bool kp = drop_uniform(a, seq, hd, S, query, key) < keep;
             pdv = kp ? p / keep : 0.f;
             dpv = kp ? dpv / keep : 0.f;
           }

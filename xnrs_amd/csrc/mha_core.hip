@@ -128,8 +128,7 @@ __global__ __launch_bounds__(256) void mha_core_kernel(MhaCoreArgs a, int QT, in
       float p = acc[kt][r] * inv_sum;
       if (a.dropout_p > 0.f) {  // nn.Dropout on the probabilities (layers.py:148), train mode only
         const int key = kt * 16 + 4 * g + r;
-        const uint64_t idx = ((uint64_t)(seq * a.n_heads + hd) * S + (uint64_t)query) * S + (uint64_t)key;
-        p = (uniform01(drop_seed(a), idx) < keep) ? p / keep : 0.f;
+        p = (drop_uniform(a, seq, hd, S, query, key) < keep) ? p / keep : 0.f;
       }
       acc[kt][r] = p;
     }
@@ -270,8 +269,7 @@ __global__ __launch_bounds__(256) void mha_core_head_kernel(MhaCoreArgs a, int64
         float p = acc[kt][r] * inv_sum;
         if (a.dropout_p > 0.f) {
           const int key = kt * 16 + 4 * g + r;
-          const uint64_t idx = ((uint64_t)(seq * a.n_heads + hd) * S + (uint64_t)query) * S + (uint64_t)key;
-          p = (uniform01(drop_seed(a), idx) < keep) ? p / keep : 0.f;
+          p = (drop_uniform(a, seq, hd, S, query, key) < keep) ? p / keep : 0.f;
         }
         acc[kt][r] = p;
       }
@@ -440,8 +438,7 @@ __global__ __launch_bounds__(256) void mha_core_lds_kernel(MhaCoreArgs a, int64_
       float p = acc[kt][r] * inv_sum;
       if (a.dropout_p > 0.f) {
         const int key = kt * 16 + 4 * g + r;
-        const uint64_t idx = ((uint64_t)(seq * a.n_heads + hd) * S + (uint64_t)query) * S + (uint64_t)key;
-        p = (uniform01(drop_seed(a), idx) < keep) ? p / keep : 0.f;
+        p = (drop_uniform(a, seq, hd, S, query, key) < keep) ? p / keep : 0.f;
       }
       acc[kt][r] = p;
     }
@@ -711,8 +708,7 @@ __global__ __launch_bounds__(256, (KTM * NFB <= 9 ? 8 : 5)) void mha_core_pair_k
   const float keep = 1.f - a.dropout_p;
   auto drop = [&](float p, int key) {
     if constexpr (DROP) {
-      const uint64_t idx = ((uint64_t)((int64_t)seq * a.n_heads + hd) * S + (uint64_t)query) * S + (uint64_t)key;
-      return (uniform01(drop_seed(a), idx) < keep) ? p / keep : 0.f;
+      return (drop_uniform(a, seq, hd, S, query, key) < keep) ? p / keep : 0.f;
     } else {
       return p;
     }

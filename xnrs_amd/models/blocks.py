@@ -206,6 +206,9 @@ class ParentRec(nn.Module):
 
     def _forward(self, history: Tuple[torch.Tensor], candidates: Tuple[torch.Tensor],
                  add_user_feats: Optional[Tuple[torch.Tensor]] = None, return_embeddings: bool = False):
+        # (Round 4 measured the candidates' encode on a second HIP stream beside the user tower, forward and -- through
+        # autograd's stream bookkeeping -- backward: bitwise the same step, but 8.28 instead of 8.17 ms for NRMS and 1.29
+        # instead of 1.20 ms for StandardRec: the event traffic costs more than the latency it hides.  One stream.)
         h, hm = self.news_encoder(history)
         c, _ = self.news_encoder(candidates)
         return self._score(h, hm, c, add_user_feats, return_embeddings)
