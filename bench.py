@@ -65,7 +65,10 @@ def news_flops(S, D, A, E, att=True, head=True, folded=False):
     D x D product per news (the A x D x D folded weight is per call, not per news)."""
     f = 2 * S * D * A + 2 * S * A + 2 * S * D
     if att:
-        f += (6 * S * D * D + 2 * D * D if folded else 8 * S * D * D) + 4 * S * S * D
+        # folded: one D x D product per news -- and none at all behind a head (round 4: W0 . Wo folded into the head's first
+        # layer, include/xnrs_hip.h xnrs_head_params.w0_folded)
+        per_news = 0 if (head and hip.FOLD_HEAD) else 2 * D * D
+        f += (6 * S * D * D + per_news if folded else 8 * S * D * D) + 4 * S * S * D
     if head:
         f += 2 * D * E + 2 * E * E
     return f

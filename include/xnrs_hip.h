@@ -84,6 +84,12 @@ typedef struct {
   const float *w0, *b0, *w2, *b2;
   int32_t out_features;
   int32_t activation;
+  /* ABI 6, optional, inference entry points with an attention stage + additive pooler in the same call: the head's first
+   * layer folded behind the out-projection (layers.py:154 under news_encoding.py:27-31),
+   *   w0_folded [E, D] = W0 . Wo      b0_rowvec [E] = W0 . bo      (xnrs_fold_head_weights; exact algebra)
+   * so that the per-news out-projection product disappears: head_1 = act((W0 Wo) po + (W0 bo) s + b0) with po the pooled
+   * attention rows and s the sum of the pooling weights.  NULL = out-projection, then the head as written. */
+  const float *w0_folded, *b0_rowvec;
 } xnrs_head_params;
 
 int32_t xnrs_abi_version(void);
@@ -141,6 +147,12 @@ int32_t xnrs_text_encoder_fwd(const float *x, const float *m, const int32_t *ids
 size_t xnrs_fold_weights_workspace_bytes(int32_t D, int32_t A);
 int32_t xnrs_fold_weights(const xnrs_mha_params *att, const xnrs_additive_params *pool, int32_t D, float *w1f, float *b1f,
                           void *ws, size_t ws_bytes, void *stream);
+
+/* The folded first head layer for xnrs_head_params.w0_folded / b0_rowvec (b0v may be NULL when att->bo is NULL).
+ * ws: xnrs_fold_head_weights_workspace_bytes(D, E) of scratch. */
+size_t xnrs_fold_head_weights_workspace_bytes(int32_t D, int32_t E);
+int32_t xnrs_fold_head_weights(const xnrs_mha_params *att, const xnrs_head_params *head, int32_t D, float *w0f, float *b0v,
+                               void *ws, size_t ws_bytes, void *stream);
 
 /* ---- TextEncoder.forward without the padding work (inference) --------------------------------
  * Same result as xnrs_text_encoder_fwd for 0/1 masks, computing only what can reach the output

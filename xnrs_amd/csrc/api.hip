@@ -245,6 +245,35 @@ hipError_t pooled_out_projection(const float* po, const float* s, const xnrs_mha
   return launch_add_rowscaled_bias(dst, D, s, att->bo, n, D, stream);
 }
 
+// The tail of a pooled encoder call: [out-projection behind the pooling] -> [head].  One definition for the padded, the
+// host-compacted and the device-compacted pipelines, so that they stay bit for bit equal.
+//   fold && head && head->w0_folded (inference, fp32 GEMM mode): the out-projection is folded INTO the head's first layer,
+//     W0 (Wo po + bo s) + b0 = (W0 Wo) po + (W0 bo) s + b0 -- the caller's cached pair (xnrs_fold_head_weights) -- and the
+//     n x D x D product disappears (0.31 of the 44.4 ms benchmark step, 13 of the 299 us of configs[1]); the rank-1 term
+//     rides in the GEMM's epilogue like bo s did.  Exact algebra, another rounding order (~1e-6).
+//   otherwise: pooled = Wo po + bo s, then the head's two layers as written (news_encoding.py:27-31).
+int32_t pooled_tail(bool fold, const float* pob, const float* asum, const xnrs_mha_params* att, const xnrs_head_params* head,
+                    float* pb, float* hb, float* y, int64_t n, int D, int E, const unsigned short* wo_planes, bool train,
+                    hipStream_t stream) {
+  const bool fold_head = fold && head && !train && head->w0_folded && gemm_mode() == 0 && (!att->bo || head->b0_rowvec);
+  if (fold && !fold_head) {
+    ProfScope ps(2, 2.0 * n * (double)D * D, stream);
+    XNRS_TRY(pooled_out_projection(pob, asum, att, head ? pb : y, n, D, wo_planes, stream));
+  }
+  if (head) {
+    ProfScope ps(5, 2.0 * n * ((double)D * E + (double)E * E), stream);
+    GemmArgs g1 = gemm1(fold_head ? pob : pb, nullptr, 0, D, fold_head ? head->w0_folded : head->w0, head->b0, hb, E, n, E, D,
+                        head->activation);
+    if (fold_head && att->bo) {
+      g1.rowscale = asum;
+      g1.rowscale_vec = head->b0_rowvec;
+    }
+    XNRS_TRY(launch_gemm_f32(g1, stream));
+    XNRS_TRY(launch_gemm_f32(gemm1(hb, nullptr, 0, E, head->w2, head->b2, y, E, n, E, E, XNRS_ACT_NONE), stream));
+  }
+  return XNRS_OK;
+}
+
 // x:(n_seq,L,D) [or table + ids], m:(n_seq,L) [or table mask] -> y
 //   pooled == false: y:(n_seq,L,D) = att(x)            (MultiHeadAttention alone)
 //   pooled == true : y:(n_seq,E')  = head(pool(att(x)))
@@ -614,17 +643,8 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
       }
     }
   }
-  if (fold) {  // pooled = Wo (sum_i a_i O_i) + bo (sum_i a_i): one out-projection per sequence, the bias term in its epilogue
-    float* dst = head ? pb : y;
-    ProfScope ps(2, 2.0 * n_seq * (double)D * D, stream);
-    XNRS_TRY(pooled_out_projection(pob, asum, att, dst, n_seq, D, po, stream));
-  }
-  if (pooled && head) {
-    ProfScope ps(5, 2.0 * n_seq * ((double)D * E + (double)E * E), stream);
-    XNRS_TRY(launch_gemm_f32(gemm1(pb, nullptr, 0, D, head->w0, head->b0, hb, E, n_seq, E, D, head->activation), stream));
-    XNRS_TRY(launch_gemm_f32(gemm1(hb, nullptr, 0, E, head->w2, head->b2, y, E, n_seq, E, E, XNRS_ACT_NONE), stream));
-  }
-  return XNRS_OK;
+  // pooled = Wo (sum_i a_i O_i) + bo (sum_i a_i): one out-projection per sequence (or folded into the head), then the head
+  return pooled_tail(fold, pob, asum, att, pooled ? head : nullptr, pb, hb, y, n_seq, D, E, po, train, stream);
 }
 
 }  // namespace
@@ -902,17 +922,7 @@ int32_t xnrs_text_encoder_fwd_unpadded(const float* x, const int32_t* ids, int64
     ProfScope ps(4, 2.0 * n_valid * (double)(A + D), stream);
     XNRS_TRY(launch_additive_pool(pa, stream));
   }
-  if (fold) {
-    float* dst = head ? pb : y;
-    ProfScope ps(2, 2.0 * n_news * (double)D * D, stream);
-    XNRS_TRY(pooled_out_projection(pob, asum, att, dst, n_news, D, nullptr, stream));
-  }
-  if (head) {
-    ProfScope ps(5, 2.0 * n_news * ((double)D * E + (double)E * E), stream);
-    XNRS_TRY(launch_gemm_f32(gemm1(pb, nullptr, 0, D, head->w0, head->b0, hb, E, n_news, E, D, head->activation), stream));
-    XNRS_TRY(launch_gemm_f32(gemm1(hb, nullptr, 0, E, head->w2, head->b2, y, E, n_news, E, E, XNRS_ACT_NONE), stream));
-  }
-  return XNRS_OK;
+  return pooled_tail(fold, pob, asum, att, head, pb, hb, y, n_news, D, E, nullptr, false, stream);
 }
 
 // ---- the padding-free encoder with the row lists built ON THE DEVICE (no host sync: hipGraph-capturable)
@@ -1110,15 +1120,9 @@ int32_t xnrs_text_encoder_fwd_compact(const float* x, const float* m, const int3
       XNRS_TRY(launch_additive_pool(pa, stream));
     }
   }
-  if (fold) {
-    float* dst = head ? pb : y;
-    ProfScope ps(2, 2.0 * n_news * (double)D * D, stream);
-    XNRS_TRY(pooled_out_projection(pob, asum, att, dst, n_news, D, nullptr, stream));
-  }
-  if (head) {
-    ProfScope ps(5, 2.0 * n_news * ((double)D * E + (double)E * E), stream);
-    XNRS_TRY(launch_gemm_f32(gemm1(pb, nullptr, 0, D, head->w0, head->b0, hb, E, n_news, E, D, head->activation), stream));
-    XNRS_TRY(launch_gemm_f32(gemm1(hb, nullptr, 0, E, head->w2, head->b2, y, E, n_news, E, E, XNRS_ACT_NONE), stream));
+  {
+    const int32_t rc = pooled_tail(fold, pob, asum, att, head, pb, hb, y, n_news, D, E, nullptr, false, stream);
+    if (rc != XNRS_OK) return rc;
   }
   // a mask value other than 0 / 1 in any pass: NaN over the whole result (a ReLU head would swallow a NaN fed in earlier)
   const int n_pass = (int)((n_news + p.chunk - 1) / p.chunk);
@@ -1162,6 +1166,38 @@ int32_t xnrs_fold_weights(const xnrs_mha_params* att, const xnrs_additive_params
     if (pool->b1) XNRS_TRY(hipMemcpyAsync(b1f, pool->b1, (size_t)pool->hidden * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     else XNRS_TRY(hipMemsetAsync(b1f, 0, (size_t)pool->hidden * sizeof(float), (hipStream_t)stream));
   }
+  return XNRS_OK;
+}
+
+size_t xnrs_fold_head_weights_workspace_bytes(int32_t D, int32_t E) {
+  return (D > 0 && E > 0) ? (size_t)FOLD_SPLITS * (size_t)E * (size_t)D * sizeof(float) : 0;
+}
+
+int32_t xnrs_fold_head_weights(const xnrs_mha_params* att, const xnrs_head_params* head, int32_t D, float* w0f, float* b0v,
+                               void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!att || !head || !att->wo || !head->w0 || !w0f || D <= 0 || head->out_features <= 0) return XNRS_EINVAL;
+  if (att->bo && !b0v) return XNRS_EINVAL;
+  const int E = head->out_features;
+  if (ws_bytes < xnrs_fold_head_weights_workspace_bytes(D, E) || !ws) return XNRS_EWORKSPACE;
+  GemmArgs g{};  // w0f[E][D] = W0[E][D] . Wo[D][D]   (B k-major: its row index is the contraction index)
+  g.A = head->w0;
+  g.lda = D;
+  g.W[0] = att->wo;
+  g.b_kn = 1;
+  g.ldw = D;
+  g.nseg = 1;
+  g.Nseg = D;
+  g.C = w0f;
+  g.ldc = D;
+  g.M = E;
+  g.K = D;
+  if (D >= 64 * FOLD_SPLITS) {
+    g.slabs = static_cast<float*>(ws);
+    g.nsplit = FOLD_SPLITS;
+  }
+  XNRS_TRY(launch_gemm_f32(g, stream));
+  if (att->bo) XNRS_TRY(launch_fold_bias(head->w0, att->bo, nullptr, b0v, E, D, stream));  // b0v = W0 . bo
   return XNRS_OK;
 }
 

@@ -36,6 +36,7 @@ SYMBOLS = (
     "xnrs_fold_weights_workspace_bytes", "xnrs_fold_weights",
     "xnrs_text_encoder_compact_workspace_bytes", "xnrs_text_encoder_fwd_compact",
     "xnrs_seq_encoder_fwd_train_rows", "xnrs_seq_encoder_bwd_rows", "xnrs_seq_encoder_saved_qkv_offset",
+    "xnrs_fold_head_weights_workspace_bytes", "xnrs_fold_head_weights",
     "xnrs_build_id", "xnrs_row_lists_workspace_bytes", "xnrs_build_row_lists", "xnrs_set_status_word", "xnrs_status_string",
 )
 POOL_NONE = -1
@@ -59,7 +60,8 @@ class AdditiveParams(C.Structure):
 
 
 class HeadParams(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("w0", "b0", "w2", "b2")] + [("out_features", C.c_int32), ("activation", C.c_int32)]
+    _fields_ = [(n, C.c_void_p) for n in ("w0", "b0", "w2", "b2")] + [("out_features", C.c_int32), ("activation", C.c_int32)] + [
+        (n, C.c_void_p) for n in ("w0_folded", "b0_rowvec")]
 
 
 class RowLists(C.Structure):
@@ -215,6 +217,10 @@ def lib():
     l.xnrs_row_lists_workspace_bytes.argtypes = [i64]
     l.xnrs_build_row_lists.restype = i32
     l.xnrs_build_row_lists.argtypes = [p, p, i64, i32, p, p, p, p, p, p, sz, p]
+    l.xnrs_fold_head_weights_workspace_bytes.restype = sz
+    l.xnrs_fold_head_weights_workspace_bytes.argtypes = [i32, i32]
+    l.xnrs_fold_head_weights.restype = i32
+    l.xnrs_fold_head_weights.argtypes = [C.POINTER(MhaParams), C.POINTER(HeadParams), i32, p, p, p, sz, p]
     l.xnrs_set_status_word.restype = i32
     l.xnrs_set_status_word.argtypes = [p]
     l.xnrs_status_string.restype = C.c_char_p
@@ -457,12 +463,56 @@ def folded_fc1(att, pool):
     return w1f, b1f
 
 
-def head_params(head):
-    """nn.Sequential(Linear, ReLU, Linear) -> (HeadParams, keepalive list); biases may be absent."""
+def head_params(head, att=None):
+    """nn.Sequential(Linear, ReLU, Linear) -> (HeadParams, keepalive list); biases may be absent.
+    att (optional, inference with an additive pooler behind this attention stage): the head's first layer folded behind the
+    out-projection (include/xnrs_hip.h: xnrs_head_params.w0_folded) rides along -- from the per-module cache, or computed
+    for this call when XNRS_FOLD_CACHE=0 (the same kernels: the same bits)."""
     l0, l2 = head[0], head[2]
     ts = [dev_f32(l0.weight, "head.0.weight"), None if l0.bias is None else dev_f32(l0.bias, "head.0.bias"),
           dev_f32(l2.weight, "head.2.weight"), None if l2.bias is None else dev_f32(l2.bias, "head.2.bias")]
-    return HeadParams(*[None if t is None else t.data_ptr() for t in ts], l0.out_features, head_activation(head[1])), ts
+    hp = HeadParams(*[None if t is None else t.data_ptr() for t in ts], l0.out_features, head_activation(head[1]), None, None)
+    if att is not None and FOLD_HEAD:
+        w0f, b0v = folded_head(att, head)
+        hp.w0_folded = w0f.data_ptr()
+        hp.b0_rowvec = None if b0v is None else b0v.data_ptr()
+        ts = ts + [w0f, b0v]
+    return hp, ts
+
+
+#: fold the attention out-projection into the head's first layer in inference (XNRS_FOLD_HEAD=0: off; XNRS_FOLD_OUT=0 turns
+#: the whole fold off in the library, and with it this one)
+FOLD_HEAD = os.environ.get("XNRS_FOLD_HEAD", "1") != "0" and os.environ.get("XNRS_FOLD_OUT", "1") != "0"
+
+
+def folded_head(att, head):
+    """(W0 . Wo [E, D], W0 . bo [E] or None) of an (attention stage, head) pair, cached like folded_fc1."""
+    import weakref
+    src = (att.out.weight, att.out.bias, head[0].weight)
+    ver = tuple(None if t is None else (t._version, t.data_ptr(), str(t.device), t.dtype) for t in src)
+    key = (id(att), id(head), "head")
+    hit = _fold_cache.get(key) if FOLD_CACHE else None
+    if hit is not None and hit[1] == ver and all((r is None and t is None) or (r is not None and r() is t)
+                                                 for r, t in zip(hit[0], src)):
+        return hit[2], hit[3]
+    ap, keep_a = mha_params(att)
+    l0, l2 = head[0], head[2]
+    ts = [dev_f32(l0.weight, "head.0.weight"), None, dev_f32(l2.weight, "head.2.weight"), None]
+    hp = HeadParams(ts[0].data_ptr(), None, ts[2].data_ptr(), None, l0.out_features, ACT_NONE, None, None)
+    dev = l0.weight.device
+    E, D = l0.out_features, l0.in_features
+    w0f = torch.empty((E, D), dtype=torch.float32, device=dev)
+    b0v = torch.empty((E,), dtype=torch.float32, device=dev) if att.out.bias is not None else None
+    l = lib()
+    nws = l.xnrs_fold_head_weights_workspace_bytes(D, E)
+    ws = workspace(dev, nws)
+    check(l.xnrs_fold_head_weights(C.byref(ap), C.byref(hp), D, ptr(w0f), ptr(b0v), ptr(ws), nws, stream_ptr(dev)),
+          "xnrs_fold_head_weights")
+    if FOLD_CACHE:
+        if len(_fold_cache) > 64:
+            _fold_cache.clear()
+        _fold_cache[key] = (tuple(None if t is None else weakref.ref(t) for t in src), ver, w0f, b0v)
+    return w0f, b0v
 
 
 def head_activation(mod) -> int:

@@ -138,8 +138,8 @@ def text_encoder_forward(x: torch.Tensor, m: torch.Tensor, att, pooler, head, id
     if att is not None:
         ap, k2 = hip.mha_params(att, dropout_p, seed)
         keep += k2
-    if head is not None:
-        hp, k3 = hip.head_params(head)
+    if head is not None:  # (behind attention + additive pooling the out-projection folds into the head's first layer)
+        hp, k3 = hip.head_params(head, att if (pool_kind == hip.POOL_ADDITIVE and dropout_p == 0.0) else None)
         keep += k3
     A = pp.hidden if pp is not None else 0
     E = hp.out_features if hp is not None else D
@@ -185,7 +185,7 @@ def text_encoder_forward_unpadded(x: torch.Tensor, m: torch.Tensor, att, pooler,
         ap, k2 = hip.mha_params(att, 0.0, 0)
         keep += k2
     if head is not None:
-        hp, k3 = hip.head_params(head)
+        hp, k3 = hip.head_params(head, att)
         keep += k3
     A, E = pp.hidden, (hp.out_features if hp is not None else D)
     y = torch.empty((n, E), dtype=torch.float32, device=x.device)
@@ -243,7 +243,7 @@ def text_encoder_forward_compact(x: torch.Tensor, m: torch.Tensor, att, pooler, 
         ap, k2 = hip.mha_params(att, 0.0, 0)
         keep += k2
     if head is not None:
-        hp, k3 = hip.head_params(head)
+        hp, k3 = hip.head_params(head, att)
         keep += k3
     A, E = pp.hidden, (hp.out_features if hp is not None else D)
     y = torch.empty((n, E), dtype=torch.float32, device=x.device)
@@ -292,8 +292,8 @@ def user_encoder_forward(x: torch.Tensor, m: torch.Tensor, att, pooler, head, re
     if att is not None:
         ap, k2 = hip.mha_params(att, dropout_p, seed)
         keep += k2
-    if head is not None:
-        hp, k3 = hip.head_params(head)
+    if head is not None:  # (behind attention + additive pooling the out-projection folds into the head's first layer)
+        hp, k3 = hip.head_params(head, att if (pool_kind == hip.POOL_ADDITIVE and dropout_p == 0.0) else None)
         keep += k3
     A = pp.hidden if pp is not None else 0
     y = torch.empty((B, 1, E), dtype=torch.float32, device=x.device)
