@@ -548,7 +548,12 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
       ma.seed = att->seed + (uint64_t)c0 * 0x9E3779B97F4A7C15ull;
       ma.seed_dev = att->seed_dev;
       ma.stats = stats;
-      ma.skip_dead = live ? 1 : 0;  // an all-masked news: zeros instead of attention over keys nobody weights (kernels.h)
+      // an all-masked sequence: zeros instead of attention over keys nobody weights (kernels.h).  Training over row lists,
+      // and (round 4) every POOLED call with a mask: both poolers multiply a masked row by exactly 0 (layers.py:33,62-65), so
+      // the pooled vector is bit for bit the same whether such a row holds the uniform average of V or zeros -- the empty
+      // history slots of the benchmark batch (49.5 % of its news) cost the attention core nothing.  MultiHeadAttention
+      // alone (pooled == false) returns its masked rows to the caller and computes them.
+      ma.skip_dead = (live || (pooled && cm)) ? 1 : 0;
       {
         ProfScope ps(1, 4.0 * rows * (double)L * D, stream);
         XNRS_TRY(launch_mha_core(ma, stream));

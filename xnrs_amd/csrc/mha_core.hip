@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256, (KTM * NFB <= 9 ? 8 : 5)) void mha_core_pair_k
   const float* vbase = a.v + kvbase;
   const int rem = TAIL ? S - KTM * 16 : 0;  // 1..4 (launcher)
 
-  // ---- this wave's query fragments and mask value first: their latency overlaps the staging
+  // ---- this wave's mask value, the dead-sequence test, then its query fragments (their latency overlaps the staging)
   // unpadded queries (a.q_off): this sequence's live rows are the compact range [q0, q0 + nq) of q / out
   const int64_t q0 = a.q_off ? a.q_off[seq] : (int64_t)seq * S;
   const int nq = a.q_off ? (int)(a.q_off[seq + 1] - q0) : S;
@@ -533,14 +533,6 @@ __global__ __launch_bounds__(256, (KTM * NFB <= 9 ? 8 : 5)) void mha_core_pair_k
   const int c = lane & 15, g = lane >> 4;
   const int query = qt * 16 + c;
   const bool qvalid = query < nq;
-  const float* qrow = a.q_off ? a.q + (q0 + (qvalid ? query : 0)) * a.ldq + hd * dk
-                              : a.q + hbase + (int64_t)(qvalid ? query : 0) * ld;
-  f32x4 qf[NFB];
-#pragma unroll
-  for (int fb = 0; fb < NFB; ++fb) {
-    const int f0 = fb * 16 + 4 * g;
-    qf[fb] = (qvalid && f0 < dk) ? *reinterpret_cast<const f32x4*>(qrow + f0) : f32x4{0.f, 0.f, 0.f, 0.f};
-  }
   float mq = 1.f;
   if (a.mask && !a.q_off && qvalid) {
     const int64_t mrow = a.mask_gather_ids ? (int64_t)a.mask_gather_ids[seq] * S : (int64_t)seq * S;
@@ -563,6 +555,19 @@ __global__ __launch_bounds__(256, (KTM * NFB <= 9 ? 8 : 5)) void mha_core_pair_k
       }
       return;
     }
+  }
+  // (the query fragments are loaded BEHIND the dead-sequence test: since round 4 every pooled encoder call takes it, and a
+  // dead sequence -- 49.5 % of the benchmark's history slots -- must not pull its Q rows through HBM to throw them away)
+  // The same for a query TILE whose 16 rows are all masked (the 4th tile of a 30-token title in 50 slots, ...): its wave
+  // stages K / V with the others, then writes zeros instead of computing rows that the pooler multiplies by 0.
+  const bool tile_dead = a.skip_dead && a.mask && !a.q_off && !__any(qvalid && mq != 0.f);  // wave-uniform
+  const float* qrow = a.q_off ? a.q + (q0 + (qvalid ? query : 0)) * a.ldq + hd * dk
+                              : a.q + hbase + (int64_t)(qvalid ? query : 0) * ld;
+  f32x4 qf[NFB];
+#pragma unroll
+  for (int fb = 0; fb < NFB; ++fb) {
+    const int f0 = fb * 16 + 4 * g;
+    qf[fb] = (qvalid && !tile_dead && f0 < dk) ? *reinterpret_cast<const f32x4*>(qrow + f0) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
   // ---- staging.  K: thread = (chunk ch of the row, key slot ks), keys ks, ks + KP, ...; one ds_write_b128 per chunk.
@@ -623,6 +628,22 @@ __global__ __launch_bounds__(256, (KTM * NFB <= 9 ? 8 : 5)) void mha_core_pair_k
   }
   __syncthreads();
   if (qt >= QT) return;
+  if (tile_dead) {  // every query of this tile is masked: zeros (and the statistics of masked rows) instead of the products
+    if (qvalid) {
+      float* orow0 = a.out + (q0 + query) * a.ldo + hd * dk;
+#pragma unroll
+      for (int dt = 0; dt < NFB; ++dt) {
+        const int dv0 = dt * 16 + 4 * g;
+        if (dv0 < dk) *reinterpret_cast<f32x4*>(orow0 + dv0) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (a.stats && g == 0) {
+        float* sp = a.stats + (((int64_t)seq * a.n_heads + hd) * (int64_t)S + query) * 2;
+        sp[0] = -1e9f;
+        sp[1] = (float)S;
+      }
+    }
+    return;
+  }
 
   // ---- S^T = K Q^T over the full key tiles
   f32x4 acc[KTM];
