@@ -541,7 +541,7 @@ def graph_train_step(model, fn, device, steps, warmup):
         ops.set_dropout_seed_word(None)
 
 
-def train_step_extra(device, steps=5, warmup=2, model_name="NRMS", variants=True):
+def train_step_extra(device, steps=20, warmup=5, model_name="NRMS", variants=True):
     """The grad step of the reference (training.py:402-431) on the HIP path at the shipped config (batch 64, H=25, C=5,
     S=50, D=768, train mode: NRMS attention dropout 0.1): see make_train_job."""
     from xnrs_amd import autograd as AG
