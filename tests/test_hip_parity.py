@@ -598,3 +598,32 @@ def test_nonbinary_mask_on_the_device_compacted_path_sets_the_status_word():
     with pytest.raises(hip.XnrsHipError, match="mask value other than 0 / 1"):
         hip.check_status()
     hip.check_status()
+
+
+@pytest.mark.parametrize("pool", ["additive", "mean"])
+def test_attention_rows_of_masked_queries_are_not_computed_in_pooled_calls(pool):
+    """Inside a pooled encoder call the attention core leaves all-masked sequences at once and writes zeros for query tiles
+    whose 16 rows are all masked (round 4): both poolers multiply such rows by exactly 0 (layers.py:33,62-65), so news
+    vectors and masks are BIT FOR BIT those of the call that computes every attention row (XNRS_MHA_SKIP_MASKED=0) -- and
+    within the bar of the oracle.  Empty news, short titles (whole tiles masked), masks with holes, S = 50 / d_k = 16."""
+    S, D, h, E = 50, 64, 4, 32
+    pooler = layers.AdditiveAttention(D, 48) if pool == "additive" else layers.MaskedMean()
+    enc = news_encoding.TextEncoder(pooler=pooler, p_dropout=0.0, out_features=E, in_features=D, att=layers.MultiHeadAttention(h, D))
+    sd = synth.fill_state_dict({k: tuple(v.shape) for k, v in enc.state_dict().items()}, 9201)
+    enc.load_state_dict(sd)
+    enc = enc.eval().to(DEV)
+    rng = synth.rng_for(9200)
+    n = 90
+    x = torch.from_numpy(rng.standard_normal((1, n, S, D)).astype("float32"))
+    lens = rng.integers(0, S + 1, size=n)
+    lens[:6] = [0, 1, 15, 16, 17, 50]
+    m = (torch.arange(S)[None, :] < torch.from_numpy(lens)[:, None]).to(torch.float32)
+    m[40:50] *= torch.from_numpy((rng.random((10, S)) < 0.5).astype("float32"))  # holes
+    m = m.reshape(1, n, S, 1)
+    with torch.no_grad():
+        y1, hm1 = enc((x.to(DEV), m.to(DEV)))
+        with hip.knobs(XNRS_MHA_SKIP_MASKED="0"):
+            y0, hm0 = enc((x.to(DEV), m.to(DEV)))
+    assert torch.equal(y1, y0) and torch.equal(hm1, hm0)
+    yo, hmo = O.text_encoder(x, m, sd, h)
+    H.assert_close(y1, yo, what="news vectors vs oracle")

@@ -553,7 +553,7 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
       // the pooled vector is bit for bit the same whether such a row holds the uniform average of V or zeros -- the empty
       // history slots of the benchmark batch (49.5 % of its news) cost the attention core nothing.  MultiHeadAttention
       // alone (pooled == false) returns its masked rows to the caller and computes them.
-      ma.skip_dead = (live || (pooled && cm)) ? 1 : 0;
+      ma.skip_dead = (live || (pooled && cm && knobs().mha_skip_masked)) ? 1 : 0;
       {
         ProfScope ps(1, 4.0 * rows * (double)L * D, stream);
         XNRS_TRY(launch_mha_core(ma, stream));

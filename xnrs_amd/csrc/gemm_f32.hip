@@ -951,6 +951,7 @@ static Knobs read_knobs() {
   k.fast_tanh = num("XNRS_FAST_TANH", 1) != 0;
   k.additive_fused = (int)num("XNRS_ADDITIVE_FUSED", 1);
   k.af_fbuf = num("XNRS_AF_FBUF", 1) == 2 ? 2 : 1;
+  k.mha_skip_masked = num("XNRS_MHA_SKIP_MASKED", 1) != 0;
   const long long m = num("XNRS_GEMM_MODE", 0);
   k.gemm_mode_init = (m >= 0 && m <= 2) ? (int)m : 0;
   return k;
