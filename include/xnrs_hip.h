@@ -426,8 +426,9 @@ int32_t xnrs_train_fold_enabled(void);
 /* ---- sticky device status word (ABI 6; no reference counterpart) ------------------------------------------
  * Entry points that never synchronise cannot return an error for a precondition only the device can see.  They OR a bit
  * into ONE caller-owned int32 device word instead (and keep their outputs recognisably wrong: NaN), which the caller reads
- * at its next natural synchronisation point.  xnrs_set_status_word registers the word (process-global like the knobs;
- * NULL: none -- the NaN outputs are then the only signal); the caller zeroes it.  xnrs_status_string explains a value.
+ * at its next natural synchronisation point.  xnrs_set_status_word registers the word (process-global like the knobs, and
+ * bound to the device that is current at the call: launches on another device ignore it; NULL: none -- the NaN outputs
+ * are then the only signal); the caller zeroes it.  xnrs_status_string explains a value.
  *   XNRS_STATUS_NONBINARY_MASK  xnrs_text_encoder_fwd_compact met a mask value other than 0 / 1
  *   XNRS_STATUS_ROW_RANGE       (set by the Python host layer, NewsStore.gather) a table row id outside the table; the
  *                               id was clamped so that no kernel read out of bounds */

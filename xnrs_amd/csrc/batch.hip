@@ -577,9 +577,23 @@ hipError_t launch_poison(float* y, int64_t n, const int64_t* flags, int n_flags,
   return hipGetLastError();
 }
 
+// ONE word, on the device that was current when it was registered: a launch on another device gets nullptr (its kernels must
+// not be handed a pointer into this device's memory; their NaN outputs remain the signal there)
 static std::atomic<int32_t*> g_status_word{nullptr};
-int32_t* status_word() { return g_status_word.load(std::memory_order_relaxed); }
-void set_status_word(int32_t* w) { g_status_word.store(w, std::memory_order_relaxed); }
+static std::atomic<int> g_status_device{-1};
+int32_t* status_word() {
+  int32_t* w = g_status_word.load(std::memory_order_relaxed);
+  if (!w) return nullptr;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev != g_status_device.load(std::memory_order_relaxed)) return nullptr;
+  return w;
+}
+void set_status_word(int32_t* w) {
+  int dev = -1;
+  (void)hipGetDevice(&dev);
+  g_status_device.store(w ? dev : -1, std::memory_order_relaxed);
+  g_status_word.store(w, std::memory_order_relaxed);
+}
 
 hipError_t launch_compact_rows(const float* mask, const int32_t* ids, int64_t n_news, int64_t chunk, int S, int64_t* row_off,
                                int32_t* live_src, int32_t* kv_src, int32_t* kv_block, int64_t* counts, hipStream_t stream) {

@@ -348,6 +348,17 @@ __global__ __launch_bounds__(256) void mha_bwd_fused_kernel(MhaBwdArgs a) {
   // in chunk order below
   constexpr int NCH = NFB * 4;
   __shared__ float s_delta[64];
+  // round 4: the query mask and the saved softmax statistics {max, 1 / sum} of this head's queries, read from global ONCE
+  // (the q-tile loop read them per lane and per tile: 12 dependent global loads in front of every exp)
+  __shared__ float s_mq[64], s_mx[64], s_isum[64];
+  if (tid < 64) {
+    const int64_t mrow0 = a.mask ? (a.mask_gather_ids ? (int64_t)a.mask_gather_ids[seq] * S : row0) : 0;
+    const int64_t sb0 = (seq * a.n_heads + hd) * (int64_t)S;
+    const bool in = tid < S;
+    s_mq[tid] = (in && a.mask) ? a.mask[mrow0 + tid] : (in ? 1.f : 0.f);
+    s_mx[tid] = in ? a.stats[2 * (sb0 + tid)] : 0.f;
+    s_isum[tid] = in ? 1.f / a.stats[2 * (sb0 + tid) + 1] : 0.f;
+  }
   float* s_dpart = &Ts[0][0];  // 64 x NCH <= 1024 floats of the 1280
   static_assert(64 * NFB * 4 <= 4 * 16 * BWD_TLD, "delta partials must fit the transpose tiles");
   for (int idx = tid; idx < 64 * NCH; idx += 256) {
@@ -384,8 +395,6 @@ __global__ __launch_bounds__(256) void mha_bwd_fused_kernel(MhaBwdArgs a) {
   }
   const float inv_sq = a.scaled ? 1.f / sqrtf((float)dk) : 1.f;
   const float keep = 1.f - a.dropout_p;
-  const int64_t mrow = a.mask ? (a.mask_gather_ids ? (int64_t)a.mask_gather_ids[seq] * S : row0) : 0;
-  const int64_t sbase = (seq * a.n_heads + hd) * (int64_t)S;
   f32x4 dkT[NFB], dvT[NFB];
 #pragma unroll
   for (int t = 0; t < NFB; ++t) {
@@ -406,7 +415,7 @@ __global__ __launch_bounds__(256) void mha_bwd_fused_kernel(MhaBwdArgs a) {
       // all 16 queries of this tile masked (or beyond S): S / dPd / dS are dead and dO is zero, so nothing reaches
       // dK, dV or dQ -- uniform over the workgroup (depends on qt only), so the barriers below are skipped together
       const int qq = qt * 16 + c;
-      const bool lv = qq < S && a.mask[mrow + qq] != 0.f;
+      const bool lv = qq < S && s_mq[qq] != 0.f;
       if (!__any(lv)) {
         if (wave == (qt & 3) && !a.accumulate) {
           for (int idx = lane; idx < 16 * NCH; idx += 64) {
@@ -436,13 +445,12 @@ __global__ __launch_bounds__(256) void mha_bwd_fused_kernel(MhaBwdArgs a) {
         const int query = qt * 16 + 4 * g + r;
         float pdv = 0.f, dsv = 0.f;
         if (query < S && kvalid) {
-          const float mq = a.mask ? a.mask[mrow + query] : 1.f;
-          const float mx = a.stats[2 * (sbase + query)];
-          const float sum = a.stats[2 * (sbase + query) + 1];
+          const float mq = s_mq[query];
+          const float mx = s_mx[query];
           const float delta = s_delta[query];
           float sv = s[r] * inv_sq;
           if (mq == 0.f) sv = -1e9f;
-          const float p = attn_exp(sv - mx) * (1.f / sum);
+          const float p = attn_exp(sv - mx) * s_isum[query];
           float dpv = dp[r];
           pdv = p;
           if (a.dropout_p > 0.f) {
@@ -482,9 +490,10 @@ __global__ __launch_bounds__(256) void mha_bwd_fused_kernel(MhaBwdArgs a) {
       }
     }
     __syncthreads();
-    if (wave == (qt & 3)) {
-      // sum the key tiles' partials in order and store the 16 query rows (row-order 16-byte chunks)
-      for (int idx = lane; idx < 16 * NCH; idx += 64) {
+    {
+      // sum the key tiles' partials in order and store the 16 query rows (row-order 16-byte chunks).  Round 4: by ALL four
+      // waves (192 chunks over 256 threads) -- one wave did it while three waited at the barrier below
+      for (int idx = tid; idx < 16 * NCH; idx += 256) {
         const int qr = idx / NCH, f0 = (idx - qr * NCH) * 4;
         const int query = qt * 16 + qr;
         if (query < S && f0 < dk) {

@@ -243,8 +243,12 @@ def status_word(device) -> torch.Tensor:
     w = _status.get(dev.index)
     if w is None:
         w = torch.zeros(1, dtype=torch.int32, device=dev)
+        if not _status:  # the library holds ONE pointer, valid on the device current at registration (its launches on another
+            # device ignore it): the first device's word is the registered one; further devices get a host-layer-only
+            # word -- the row-range bit of NewsStore.gather still lands there, the library's own bits stay NaN-only
+            with torch.cuda.device(dev):
+                check(lib().xnrs_set_status_word(C.c_void_p(w.data_ptr())), "xnrs_set_status_word")
         _status[dev.index] = w
-        check(lib().xnrs_set_status_word(C.c_void_p(w.data_ptr())), "xnrs_set_status_word")
     return w
 
 
