@@ -461,7 +461,7 @@ int32_t xnrs_get_gemm_mode(void);
 /* ---- development knobs (no reference counterpart) ---------------------------------------------
  * Kernel-selection switches for A/B measurements and tests (XNRS_GEMM_PIPE, _BK, _BUF, _GROUP, _TILE,
  * XNRS_GEMM_SPLIT_MIN_TILES, XNRS_GEMM_DW, XNRS_MHA_LDS, XNRS_MHA_HEADWAVE, XNRS_MHA_PAIR, XNRS_MHA_BWD_FUSED,
- * XNRS_NEWS_FUSED, XNRS_NEWS_FUSED_NPW, XNRS_FOLD_OUT, XNRS_FOLD_TRAIN, XNRS_FC1_ROWDOT, XNRS_MHA_SKIP_MASKED).  The library reads
+ * XNRS_NEWS_FUSED, XNRS_NEWS_FUSED_NPW, XNRS_FOLD_OUT, XNRS_FOLD_TRAIN, XNRS_FC1_ROWDOT, XNRS_MHA_SKIP_MASKED, XNRS_BWD_SIDE_STREAM, XNRS_BWD_SIDE_MIN_ROWS).  The library reads
  * them from the environment ONCE when it is loaded -- no launch calls getenv -- and again only when this function is
  * called.  None changes a result beyond summation / association order (XNRS_FOLD_*: whether the attention
  * out-projection is applied per token row, as the reference writes it, or once per sequence behind the additive

@@ -136,6 +136,84 @@ struct ProfScope {
     if (_e != hipSuccess) return hip_rc(_e); \
   } while (0)
 
+// ---- side lane of the backward (round 4).  A backward call is two dependency chains: the input-gradient chain (dX products,
+// pooling and attention backward -- the critical path) and the weight-gradient products hanging off it (dW GEMM + split-K
+// reduction + bias sums: 3-4 launches of 7-25 us per parameter pair, most of them far too small to fill 256 CUs).  Issued on
+// one stream they serialise: 230 launches under 30 us made up 2.1 of the 8.1 ms of the NRMS grad step.  The weight-gradient
+// launches go to ONE library-owned stream per device instead, ordered behind their producers by events (fork) and joined
+// back into the caller's stream before the entry point returns -- so for the caller the call is still "everything enqueued
+// on my stream": what follows on that stream sees every result, workspaces may be reused right after the call, and a
+// hipGraph capture of the caller's stream captures the fork / join as graph edges.  No host synchronisation.  Results are
+// bitwise the same (the same launches, no atomics).  Off: XNRS_BWD_SIDE_STREAM=0, and while the launch timer is on (its stage
+// times would overlap).
+struct SideLane {
+  hipStream_t side = nullptr;
+  hipEvent_t ev[32] = {};
+  unsigned next = 0;
+  bool ok = false, tried = false;
+};
+constexpr int MAX_LANES = 64;
+SideLane g_lanes[MAX_LANES];
+std::mutex g_lane_mu;
+
+SideLane* side_lane(hipStream_t main) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_LANES) return nullptr;
+  SideLane& l = g_lanes[dev];
+  std::lock_guard<std::mutex> lk(g_lane_mu);
+  if (!l.tried) {
+    // (never created under a stream capture -- resource creation is not a capturable call: a capture whose warm-up did not
+    // run a backward simply keeps one stream)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(main, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    l.tried = true;
+    bool good = hipStreamCreateWithFlags(&l.side, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; good && i < 32; ++i) good = hipEventCreateWithFlags(&l.ev[i], hipEventDisableTiming) == hipSuccess;
+    l.ok = good;
+  }
+  return l.ok ? &l : nullptr;
+}
+
+class Fork {
+ public:
+  Fork(hipStream_t main, bool want) : main_(main) {
+    if (want && knobs().bwd_side_stream && g_prof_mask == 0) lane_ = side_lane(main);
+  }
+  // the stream for work that depends on everything issued on the caller's stream SO FAR (the caller's stream itself when the
+  // lane is off or an event call fails)
+  hipStream_t after_main() {
+    if (!lane_) return main_;
+    hipEvent_t e = next_event();
+    if (hipEventRecord(e, main_) != hipSuccess || hipStreamWaitEvent(lane_->side, e, 0) != hipSuccess) {
+      join();
+      lane_ = nullptr;
+      return main_;
+    }
+    used_ = true;
+    return lane_->side;
+  }
+  // the caller's stream waits for the lane (idempotent; the destructor calls it on every return path)
+  void join() {
+    if (!lane_ || !used_) return;
+    hipEvent_t e = next_event();
+    if (hipEventRecord(e, lane_->side) == hipSuccess) (void)hipStreamWaitEvent(main_, e, 0);
+    used_ = false;
+  }
+  ~Fork() { join(); }
+  Fork(const Fork&) = delete;
+  Fork& operator=(const Fork&) = delete;
+
+ private:
+  hipEvent_t next_event() {
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    return lane_->ev[lane_->next++ & 31u];
+  }
+  hipStream_t main_;
+  SideLane* lane_ = nullptr;
+  bool used_ = false;
+};
+
+
 // a row count for the launch timer's FLOP figure: the host value, or -- counts on the device, timer on for this stage --
 // read back (the timer is a measurement aid that synchronises anyway; no read happens while it is off)
 int64_t prof_count(int stage, const int64_t* cnt, int which, int64_t host_value, hipStream_t stream) {
@@ -1594,21 +1672,33 @@ int32_t xnrs_seq_encoder_bwd_rows(const float* x, const float* m, const int32_t*
   const int32_t* kvx = kvl ? (rl->kv_src_rows ? rl->kv_src_rows : rl->kv_rows) : nullptr;
   const bool fold = att && pooled && additive && fold_wanted(knobs().fold_train);  // = the forward's decision
 
+  // weight-gradient launches go to the side lane (SideLane above): `sw` = that stream, re-ordered behind the caller's stream
+  // (after_main) wherever the input-gradient chain has produced what the next weight gradients read.  slabs / csum are
+  // touched by lane launches only, wt by the chain only.
+  // Where it pays (tools/bench_side_lane.py, B = 64 grad steps): the NRMS step, GPU-bound at ~30 us per launch, 7.93 -> 7.64
+  // ms; the attention-free towers of StandardRec / NAML (1.4 / 3.3 ms steps of ~100 launches: the HOST is the limit there and
+  // the fork / join calls only add to it) +6 % / +2 % -- so the lane serves towers with an attention stage and at least
+  // XNRS_BWD_SIDE_MIN_ROWS token rows.
+  Fork fk(stream, att != nullptr && rows >= knobs().bwd_side_min_rows);
+  hipStream_t sw = stream;
+
   // gradient w.r.t. the sequence rows that fed the pooler (att output, or x itself)
   const float* dseq_src = nullptr;  // [rows, D]
   if (pooled) {
     // ---- head: y = W2 relu(W0 p + b0) + b2
     const float* dpool = dy;  // [n_seq, D]
     if (head) {
+      sw = fk.after_main();  // (dy: produced on the caller's stream before this call)
       if (g_head && g_head->w2)
-        XNRS_TRY(gemm_dw(dy, E, hb, nullptr, 0, E, g_head->w2, n_seq, E, E, slabs, stream, nullptr, nullptr, 0, g_head->b2, csum));
-      else if (g_head && g_head->b2) XNRS_TRY(launch_colsum(dy, E, nullptr, n_seq, E, g_head->b2, csum, stream));
+        XNRS_TRY(gemm_dw(dy, E, hb, nullptr, 0, E, g_head->w2, n_seq, E, E, slabs, sw, nullptr, nullptr, 0, g_head->b2, csum));
+      else if (g_head && g_head->b2) XNRS_TRY(launch_colsum(dy, E, nullptr, n_seq, E, g_head->b2, csum, sw));
       // f'(saved activation): relu' (aux mode 2), tanh' = 1 - t^2 (1), identity (0)
       const int hmode = head->activation == XNRS_ACT_RELU ? 2 : (head->activation == XNRS_ACT_TANH ? 1 : 0);
       XNRS_TRY(gemm_dx(dy, E, head->w2, dh, E, n_seq, E, E, hmode ? hb : nullptr, E, hmode, 0, stream, wt));
+      sw = fk.after_main();  // dh
       if (g_head && g_head->w0)
-        XNRS_TRY(gemm_dw(dh, E, pb, nullptr, 0, D, g_head->w0, n_seq, E, D, slabs, stream, nullptr, nullptr, 0, g_head->b0, csum));
-      else if (g_head && g_head->b0) XNRS_TRY(launch_colsum(dh, E, nullptr, n_seq, E, g_head->b0, csum, stream));
+        XNRS_TRY(gemm_dw(dh, E, pb, nullptr, 0, D, g_head->w0, n_seq, E, D, slabs, sw, nullptr, nullptr, 0, g_head->b0, csum));
+      else if (g_head && g_head->b0) XNRS_TRY(launch_colsum(dh, E, nullptr, n_seq, E, g_head->b0, csum, sw));
       XNRS_TRY(gemm_dx(dh, E, head->w0, dp, D, n_seq, E, D, nullptr, 0, 0, 0, stream, wt));
       dpool = dp;
     }
@@ -1647,24 +1737,25 @@ int32_t xnrs_seq_encoder_bwd_rows(const float* x, const float* m, const int32_t*
       pa.D = D;
       pa.A = A;
       XNRS_TRY(launch_additive_pool_bwd(pa, stream));
-      if (g_pool && g_pool->w2) XNRS_TRY(launch_colsum(t, A, de, rows, A, g_pool->w2, csum, stream));
-      if (g_pool && g_pool->b2) XNRS_TRY(launch_colsum(de, 1, nullptr, rows, 1, g_pool->b2, csum, stream));
-      XNRS_TRY(gemm_dw(dpre, A, o, nullptr, 0, D, dwf, rows, A, D, slabs, stream, lv, lv, n_live, dbf, csum, cnt_live));
+      sw = fk.after_main();  // dpool (dp), dpre, de
       XNRS_TRY(gemm_dx(dpre, A, wf, docat, D, rows, A, D, nullptr, 0, 0, /*accumulate*/ 1, stream, wt, lv, n_live, cnt_live));
+      if (g_pool && g_pool->w2) XNRS_TRY(launch_colsum(t, A, de, rows, A, g_pool->w2, csum, sw));
+      if (g_pool && g_pool->b2) XNRS_TRY(launch_colsum(de, 1, nullptr, rows, 1, g_pool->b2, csum, sw));
+      XNRS_TRY(gemm_dw(dpre, A, o, nullptr, 0, D, dwf, rows, A, D, slabs, sw, lv, lv, n_live, dbf, csum, cnt_live));
       if (g_pool && g_pool->w1) {
-        XNRS_TRY(launch_gemm_f32(gemm1(dwf, nullptr, 0, D, att->wo, nullptr, g_pool->w1, D, A, D, D, XNRS_ACT_NONE), stream));
-        if (att->bo) XNRS_TRY(launch_add_rowscaled_bias(g_pool->w1, D, dbf, att->bo, A, D, stream));
+        XNRS_TRY(launch_gemm_f32(gemm1(dwf, nullptr, 0, D, att->wo, nullptr, g_pool->w1, D, A, D, D, XNRS_ACT_NONE), sw));
+        if (att->bo) XNRS_TRY(launch_add_rowscaled_bias(g_pool->w1, D, dbf, att->bo, A, D, sw));
       }
       if (g_pool && g_pool->b1)
-        XNRS_TRY(hipMemcpyAsync(g_pool->b1, dbf, (size_t)A * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        XNRS_TRY(hipMemcpyAsync(g_pool->b1, dbf, (size_t)A * sizeof(float), hipMemcpyDeviceToDevice, sw));
       // dWo = dp^T po + W1^T dW' as two products (the second accumulates), dbo = sum_n s_n dp_n + sum_a db'_a W1[a,:] as ONE
       // column sum over the two row blocks (round 3 staged [dp; W1] and [po; dW'] with six device copies per call)
       if (g_att && g_att->wo) {
-        XNRS_TRY(gemm_dw(dpool, D, pob, nullptr, 0, D, g_att->wo, n_seq, D, D, slabs, stream));
-        XNRS_TRY(gemm_dw(pool->w1, D, dwf, nullptr, 0, D, g_att->wo, A, D, D, slabs, stream, nullptr, nullptr, 0, nullptr, nullptr,
+        XNRS_TRY(gemm_dw(dpool, D, pob, nullptr, 0, D, g_att->wo, n_seq, D, D, slabs, sw));
+        XNRS_TRY(gemm_dw(pool->w1, D, dwf, nullptr, 0, D, g_att->wo, A, D, D, slabs, sw, nullptr, nullptr, 0, nullptr, nullptr,
                          nullptr, /*accumulate*/ 1));
       }
-      if (g_att && g_att->bo) XNRS_TRY(launch_colsum2(dpool, D, asum, n_seq, pool->w1, D, dbf, A, D, g_att->bo, csum, stream));
+      if (g_att && g_att->bo) XNRS_TRY(launch_colsum2(dpool, D, asum, n_seq, pool->w1, D, dbf, A, D, g_att->bo, csum, sw));
 
     } else {
     const float* seq = att ? yatt : x;
@@ -1689,13 +1780,14 @@ int32_t xnrs_seq_encoder_bwd_rows(const float* x, const float* m, const int32_t*
       pa.D = D;
       pa.A = A;
       XNRS_TRY(launch_additive_pool_bwd(pa, stream));
-      if (g_pool && g_pool->w2) XNRS_TRY(launch_colsum(t, A, de, rows, A, g_pool->w2, csum, stream));
-      if (g_pool && g_pool->b2) XNRS_TRY(launch_colsum(de, 1, nullptr, rows, 1, g_pool->b2, csum, stream));
+      sw = fk.after_main();  // dpre, de
+      if (g_pool && g_pool->w2) XNRS_TRY(launch_colsum(t, A, de, rows, A, g_pool->w2, csum, sw));
+      if (g_pool && g_pool->b2) XNRS_TRY(launch_colsum(de, 1, nullptr, rows, 1, g_pool->b2, csum, sw));
       if (g_pool && g_pool->w1 && live)  // rows of dpre through lv; rows of seq through lv (yatt) or lvx (x / table rows)
-        XNRS_TRY(gemm_dw(dpre, A, seq, nullptr, 0, D, g_pool->w1, rows, A, D, slabs, stream, lv, att ? lv : lvx, n_live, g_pool->b1, csum, cnt_live));
+        XNRS_TRY(gemm_dw(dpre, A, seq, nullptr, 0, D, g_pool->w1, rows, A, D, slabs, sw, lv, att ? lv : lvx, n_live, g_pool->b1, csum, cnt_live));
       else if (g_pool && g_pool->w1)
-        XNRS_TRY(gemm_dw(dpre, A, seq, seq_ids, L, D, g_pool->w1, rows, A, D, slabs, stream, nullptr, nullptr, 0, g_pool->b1, csum));
-      else if (g_pool && g_pool->b1) XNRS_TRY(launch_colsum(dpre, A, nullptr, rows, A, g_pool->b1, csum, stream));
+        XNRS_TRY(gemm_dw(dpre, A, seq, seq_ids, L, D, g_pool->w1, rows, A, D, slabs, sw, nullptr, nullptr, 0, g_pool->b1, csum));
+      else if (g_pool && g_pool->b1) XNRS_TRY(launch_colsum(dpre, A, nullptr, rows, A, g_pool->b1, csum, sw));
       if (need_dseq)
         XNRS_TRY(gemm_dx(dpre, A, pool->w1, dseq_dst, D, rows, A, D, nullptr, 0, 0, /*accumulate*/ 1, stream, wt, lv, n_live, cnt_live));
     } else if (need_dseq) {
@@ -1710,9 +1802,10 @@ int32_t xnrs_seq_encoder_bwd_rows(const float* x, const float* m, const int32_t*
 
   // ---- out projection: yatt = O Wo^T + bo   (folded: docat and the Wo / bo gradients are complete already)
   if (!fold) {
+    sw = fk.after_main();  // the sequence-row gradient is complete (pooler: its fc1 dX product accumulated into it)
     if (g_att && g_att->wo)
-      XNRS_TRY(gemm_dw(dseq_src, D, o, nullptr, 0, D, g_att->wo, rows, D, D, slabs, stream, lv, lv, n_live, g_att->bo, csum, cnt_live));
-    else if (g_att && g_att->bo) XNRS_TRY(launch_colsum(dseq_src, D, nullptr, rows, D, g_att->bo, csum, stream));
+      XNRS_TRY(gemm_dw(dseq_src, D, o, nullptr, 0, D, g_att->wo, rows, D, D, slabs, sw, lv, lv, n_live, g_att->bo, csum, cnt_live));
+    else if (g_att && g_att->bo) XNRS_TRY(launch_colsum(dseq_src, D, nullptr, rows, D, g_att->bo, csum, sw));
     if (live) XNRS_TRY(hipMemsetAsync(docat, 0, (size_t)rows * D * sizeof(float), stream));  // dO of a masked row is zero
     XNRS_TRY(gemm_dx(dseq_src, D, att->wo, docat, D, rows, D, D, nullptr, 0, 0, 0, stream, wt, lv, n_live, cnt_live));
   }
@@ -1754,6 +1847,7 @@ int32_t xnrs_seq_encoder_bwd_rows(const float* x, const float* m, const int32_t*
     XNRS_TRY(launch_mha_bwd(mb, stream));
   }
   if (rl->dqkv_mode == XNRS_DQKV_DEFER) return XNRS_OK;  // the merging call computes the projection gradients from the sum
+  sw = fk.after_main();  // dQ | dK | dV
   // ---- Q/K/V projections
   float* gw[3] = {g_att ? g_att->wq : nullptr, g_att ? g_att->wk : nullptr, g_att ? g_att->wv : nullptr};
   float* gb[3] = {g_att ? g_att->bq : nullptr, g_att ? g_att->bk : nullptr, g_att ? g_att->bv : nullptr};
@@ -1765,10 +1859,10 @@ int32_t xnrs_seq_encoder_bwd_rows(const float* x, const float* m, const int32_t*
   if (gw[1] && gw[2] && !dx && (!gb[1] == !gb[2])) {
     const float* dkv = dqkv + D;
     if (kvl)
-      XNRS_TRY(gemm_dw(dkv, 3 * (int64_t)D, x, nullptr, 0, D, gw[1], rows, 2 * D, D, slabs, stream, kvr, kvx, n_kv, gb[1], csum, cnt_kv,
+      XNRS_TRY(gemm_dw(dkv, 3 * (int64_t)D, x, nullptr, 0, D, gw[1], rows, 2 * D, D, slabs, sw, kvr, kvx, n_kv, gb[1], csum, cnt_kv,
                        0, gw[2], gb[2], D));
     else
-      XNRS_TRY(gemm_dw(dkv, 3 * (int64_t)D, x, ids, L, D, gw[1], rows, 2 * D, D, slabs, stream, nullptr, nullptr, 0, gb[1], csum,
+      XNRS_TRY(gemm_dw(dkv, 3 * (int64_t)D, x, ids, L, D, gw[1], rows, 2 * D, D, slabs, sw, nullptr, nullptr, 0, gb[1], csum,
                        nullptr, 0, gw[2], gb[2], D));
     kv_merged = true;
   }
@@ -1777,13 +1871,13 @@ int32_t xnrs_seq_encoder_bwd_rows(const float* x, const float* m, const int32_t*
     if (kv_merged && s3 > 0) continue;
     if (gw[s3]) {
       if (s3 == 0 && live)  // dQ is zero on masked rows; dK / dV are not (padded tokens are keys) ...
-        XNRS_TRY(gemm_dw(dpart, 3 * (int64_t)D, x, nullptr, 0, D, gw[s3], rows, D, D, slabs, stream, lv, lvx, n_live, gb[s3], csum, cnt_live));
+        XNRS_TRY(gemm_dw(dpart, 3 * (int64_t)D, x, nullptr, 0, D, gw[s3], rows, D, D, slabs, sw, lv, lvx, n_live, gb[s3], csum, cnt_live));
       else if (s3 > 0 && kvl)  // ... except on the rows of an all-masked news
-        XNRS_TRY(gemm_dw(dpart, 3 * (int64_t)D, x, nullptr, 0, D, gw[s3], rows, D, D, slabs, stream, kvr, kvx, n_kv, gb[s3], csum, cnt_kv));
+        XNRS_TRY(gemm_dw(dpart, 3 * (int64_t)D, x, nullptr, 0, D, gw[s3], rows, D, D, slabs, sw, kvr, kvx, n_kv, gb[s3], csum, cnt_kv));
       else
-        XNRS_TRY(gemm_dw(dpart, 3 * (int64_t)D, x, ids, L, D, gw[s3], rows, D, D, slabs, stream, nullptr, nullptr, 0, gb[s3], csum));
+        XNRS_TRY(gemm_dw(dpart, 3 * (int64_t)D, x, ids, L, D, gw[s3], rows, D, D, slabs, sw, nullptr, nullptr, 0, gb[s3], csum));
     } else if (gb[s3]) {
-      XNRS_TRY(launch_colsum(dpart, 3 * (int64_t)D, nullptr, rows, D, gb[s3], csum, stream));
+      XNRS_TRY(launch_colsum(dpart, 3 * (int64_t)D, nullptr, rows, D, gb[s3], csum, sw));
     }
     if (dx) XNRS_TRY(gemm_dx(dpart, 3 * (int64_t)D, wqkv[s3], dx, D, rows, D, D, nullptr, 0, 0, s3 > 0 ? 1 : 0, stream, wt));
   }

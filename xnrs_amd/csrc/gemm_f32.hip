@@ -952,6 +952,8 @@ static Knobs read_knobs() {
   k.additive_fused = (int)num("XNRS_ADDITIVE_FUSED", 1);
   k.af_fbuf = num("XNRS_AF_FBUF", 1) == 2 ? 2 : 1;
   k.mha_skip_masked = num("XNRS_MHA_SKIP_MASKED", 1) != 0;
+  k.bwd_side_stream = num("XNRS_BWD_SIDE_STREAM", 1) != 0;
+  k.bwd_side_min_rows = num("XNRS_BWD_SIDE_MIN_ROWS", 0);
   const long long m = num("XNRS_GEMM_MODE", 0);
   k.gemm_mode_init = (m >= 0 && m <= 2) ? (int)m : 0;
   return k;

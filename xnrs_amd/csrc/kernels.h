@@ -39,6 +39,8 @@ struct Knobs {
   int additive_fused = 1;       // XNRS_ADDITIVE_FUSED=0|2: never / whenever eligible use the one-launch additive encoder
                                 // (additive_fused.hip); 1 = from a batch that fills the chip (results are bitwise equal)
   int af_fbuf = 1;              // XNRS_AF_FBUF=1|2: MFMA fragment register sets of that kernel
+  bool bwd_side_stream = true;  // XNRS_BWD_SIDE_STREAM=0: the backward's weight-gradient products stay on the caller's stream (api.hip: SideLane)
+  long long bwd_side_min_rows = 0;  // XNRS_BWD_SIDE_MIN_ROWS: ... for attention towers of at least this many token rows
   bool mha_skip_masked = true;  // XNRS_MHA_SKIP_MASKED=0: pooled encoder calls compute the attention rows of all-masked sequences
                                 // and query tiles too (the pooler multiplies them by 0: bitwise the same pooled vectors)
 };
