@@ -12,12 +12,15 @@
  *   - all tensors are contiguous row-major fp32 DEVICE pointers unless stated; masks are fp32 0/1
  *     exactly like the reference (news_encoding.py:34-50); ids are int32 device pointers.
  *   - nn.Linear weights keep the reference layout W[out][in] (K-contiguous), bias[out] or NULL.
- *   - no allocation and no host sync: the caller supplies the workspace (size from the
+ *   - no device-memory allocation and no host sync: the caller supplies the workspace (size from the
  *     *_workspace_bytes query) and a hipStream_t (as void*; NULL = default stream).  Safe to capture
- *     into a hipGraph.
+ *     into a hipGraph.  Every result of a call is ordered on THAT stream when the call returns; the
+ *     backward entry points may fork weight-gradient launches onto a library-owned stream and join
+ *     them back by events inside the call (one stream + 32 events per device, created at the first
+ *     eager backward; XNRS_BWD_SIDE_STREAM=0: never).
  *   - process-global state (documented at its entry points, nothing else exists): the forward-GEMM
- *     arithmetic mode (xnrs_set_gemm_mode), the development knobs (xnrs_reload_knobs) and the optional
- *     launch timer (xnrs_profile_*).  Encode / score calls on different streams may run from different
+ *     arithmetic mode (xnrs_set_gemm_mode), the development knobs (xnrs_reload_knobs), the optional
+ *     launch timer (xnrs_profile_*), the status word (xnrs_set_status_word) and that side stream.  Encode / score calls on different streams may run from different
  *     threads; changing one of the three while another thread launches is the caller's race.
  *   - return value: 0 = ok; >0 = hipError_t of the failed launch; <0 = XNRS_E* argument error.
  *     xnrs_error_string() explains either.

@@ -1,6 +1,7 @@
 // extern "C" entry points of libxnrs_hip.so (declared in include/xnrs_hip.h) and the host-side
-// orchestration of the kernel pipeline.  No allocation and no sync: everything is enqueued on the caller's
-// stream into the caller's workspace (hipGraph-capturable).  Process-global state, all of it here or in
+// orchestration of the kernel pipeline.  No device allocation and no sync: everything is enqueued on the caller's
+// stream into the caller's workspace (hipGraph-capturable) -- or, for the backward's weight gradients, on a side stream
+// forked from and joined back into the caller's stream inside the call (SideLane below).  Process-global state, all of it here or in
 // gemm_f32.hip and none of it touched by a plain encode/score call: the forward-GEMM arithmetic mode
 // (xnrs_set_gemm_mode, an atomic int), the development knobs (read once at load, xnrs_reload_knobs) and the
 // optional launch timer (xnrs_profile_*, mutex-guarded, off by default).
