@@ -306,3 +306,33 @@ def test_shared_projection_is_bitwise_neutral_with_attention_dropout_on(monkeypa
     for k in g0:
         assert torch.equal(g0[k], g1[k]), k
 
+
+
+@pytest.mark.parametrize("model_name", ["NRMS", "standard"])
+def test_side_lane_of_the_backward_is_bitwise_neutral(model_name, monkeypatch):
+    """The backward's weight-gradient launches on the library's side stream (api.hip SideLane: forked from and joined back
+    into the caller's stream inside the call) against the same step on one stream: the same launches, so loss and every
+    gradient bit for bit -- also when the caller's stream is not the default one, and with nothing but the call's own join
+    between the backward and the gradients' first reader (the clone right behind it)."""
+    c = dict(model=model_name, B=8, H=12, C=3, S=50, D=64, h=4, E=32, bias=False, seed=4707, min_len=3)
+    from xnrs_amd import autograd as AG
+    monkeypatch.setattr(AG, "LIVE_ROWS_MIN", 1)
+    model = _nrms(c, 0.1)
+    batch = synth.batch_to(cases.model_batch(c), DEV)
+    labels = torch.tensor([0, 1, 0, 2, 1, 0, 2, 2], device=DEV)
+    with hip.knobs(XNRS_BWD_SIDE_STREAM="0"):
+        l0, g0 = _step(model, batch, labels)
+    with hip.knobs(XNRS_BWD_SIDE_STREAM="1", XNRS_BWD_SIDE_MIN_ROWS="0"):
+        for rep in range(3):  # (repeated: a missing join would show as a stale or half-written gradient now and then)
+            l1, g1 = _step(model, batch, labels)
+            assert torch.equal(l0, l1) and g0.keys() == g1.keys()
+            for k in g0:
+                assert torch.equal(g0[k], g1[k]), (rep, k)
+        side = torch.cuda.Stream(device=DEV)
+        side.wait_stream(torch.cuda.current_stream(DEV))
+        with torch.cuda.stream(side):
+            l2, g2 = _step(model, batch, labels)
+        side.synchronize()
+        assert torch.equal(l0, l2)
+        for k in g0:
+            assert torch.equal(g0[k], g2[k]), k

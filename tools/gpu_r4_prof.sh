@@ -8,6 +8,7 @@ rm -rf $OUT; mkdir -p $OUT
 cd $R
 timeout -k 10 600 python -m pytest tests -m gpu -q > $OUT/tests.log 2>&1; echo "tests rc=$?"; tail -n 2 $OUT/tests.log
 timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -n 1
+timeout -k 10 300 python3 tools/soak_determinism.py 25 2>&1 | grep -v amdgpu.ids | tee $OUT/soak_determinism.txt
 timeout -k 10 900 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err; echo "bench rc=$?"
 for t in nrms standard naml; do
   timeout -k 10 300 python bench.py --train $t --steps 20 --warmup 5 >> $OUT/bench_train_lines.json 2>> $OUT/bench.err
