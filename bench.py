@@ -628,6 +628,21 @@ def ig_step_extra(device, n_steps=40):
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             out[f"{name}_H{H}"] = dict(it_per_s=n_steps / dt, ms_per_it=dt / n_steps * 1e3, grads_finite=bool(torch.isfinite(g).all().item()))
+            # the same explanation with its interpolation steps as the batch dimension (xnrs_amd/explain.py): one forward +
+            # one input-gradient pass over all 100 scaled copies of the history, the same attributions
+            from xnrs_amd.explain import integrated_gradients
+            NS = 100
+            args = (model, hx.detach(), hm.detach(), cx.detach(), cm.detach())
+            integrated_gradients(*args, n_steps=NS)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                res = integrated_gradients(*args, n_steps=NS)
+            torch.cuda.synchronize()
+            dtb = (time.perf_counter() - t0) / 3
+            out[f"{name}_H{H}"]["batched_100_steps"] = dict(
+                it_per_s=NS / dtb, ms_per_explanation=dtb * 1e3, attr_finite=bool(torch.isfinite(res["attr"]).all().item()),
+                what="all 100 interpolation steps of explain.py:160-166 as ONE batch (steps are independent): same attributions")
     return out
 
 

@@ -120,6 +120,36 @@ _QKV_IMAGES = {}
 MERGE_DW = os.environ.get("XNRS_MERGE_DW", "1") != "0"
 
 
+#: torch.autograd.grad(score, inputs=[tokens]) -- integrated gradients, explain.py:160-166 -- needs no parameter gradient, but
+#: ctx.needs_input_grad only says that the parameters REQUIRE grad.  The engine knows what this pass computes: a parameter
+#: whose AccumulateGrad node it will not execute gets no weight-gradient product (two thirds of the backward of an IG step).
+#: A plain loss.backward() executes every node: nothing changes there.  XNRS_SKIP_UNUSED_DW=0: off.
+SKIP_UNUSED_DW = os.environ.get("XNRS_SKIP_UNUSED_DW", "1") != "0"
+
+
+def _wanted_inputs(ctx, is_tensor, first):
+    """[will the engine use the gradient of forward input i in THIS backward pass?] for the inputs from `first` on.
+    is_tensor: per forward input, whether a tensor was passed -- ctx.next_functions holds one edge per TENSOR input, in order
+    (non-tensor arguments and None have none)."""
+    count = len(is_tensor) - first
+    if not SKIP_UNUSED_DW or torch._C._current_graph_task_id() == -1:
+        return [True] * count
+    try:
+        nf = ctx.next_functions
+        if len(nf) != sum(1 for t in is_tensor if t):
+            return [True] * count  # (not the layout this rule assumes: compute everything)
+        out = []
+        e = 0
+        for i, t in enumerate(is_tensor):
+            fn = nf[e][0] if t else None
+            e += 1 if t else 0
+            if i >= first:
+                out.append(fn is not None and bool(torch._C._will_engine_execute_node(fn)))
+        return out
+    except (RuntimeError, AttributeError, IndexError):  # (an engine without the query: compute everything)
+        return [True] * count
+
+
 class _Pair:
     """The two training forwards that share one Q|K|V image, as seen by their backwards."""
     __slots__ = ("a", "b", "image", "task", "owner", "ran", "__weakref__")
@@ -252,9 +282,10 @@ class _SeqEncode(torch.autograd.Function):
         if want_dx and ids is not None:
             raise hip.XnrsHipError("no input gradient through an id-gathered news table")
         dx = torch.empty((n, L, D), dtype=torch.float32, device=dev) if want_dx else None
+        wanted = _wanted_inputs(ctx, [False, True, m is not None, ids is not None] + [p is not None for p in params], 4)
         grads: List[Optional[torch.Tensor]] = []
         for j, p in enumerate(params):
-            grads.append(torch.empty_like(p, dtype=torch.float32) if (p is not None and need[4 + j]) else None)
+            grads.append(torch.empty_like(p, dtype=torch.float32) if (p is not None and need[4 + j] and wanted[j]) else None)
         i = 0
         ga = gp = gh = None
         if cfg.n_heads > 0:
