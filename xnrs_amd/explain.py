@@ -49,7 +49,7 @@ def integrated_gradients(model, hist_emb: torch.Tensor, hist_att: torch.Tensor, 
     # explain.py:160: torch.arange(da, 1 + da, da) -- the same fp32 values, cut to n_steps (rounding can add one)
     alphas = torch.arange(da, 1 + da, da, device=hist_emb.device)[:n_steps]
     H, S, D = hist_emb.shape[1:]
-    int_grads = torch.zeros((H, S, D), dtype=torch.float32, device=hist_emb.device)
+    int_grads = torch.zeros((H, S, D), dtype=hist_emb.dtype, device=hist_emb.device)
     s_true = None
     if not batched:
         for a in alphas:
