@@ -359,11 +359,19 @@ def other_models_extra(device, steps=5, warmup=2):
                          frac_fp32_mfma=fl / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                          alg_gbs=B * (H + C) * (2 if name == "NAML" else 1) * (4 * S * D + 4 * S) / dt / 1e9,
                          stage_ms_per_step={k: round(v[0], 3) for k, v in st.items() if v[1]},
-                         roofline={"bound": "mfma", "kernel": "gemm_f32_kernel<...RDOT> (additive pooler: fc1 + tanh + fc2 dot)",
+                         roofline={"bound": "mfma", "kernel": "additive_fused_kernel (one launch: fc1 + tanh + fc2 dot + pooling; gemm_f32_kernel<...RDOT> "
+                                                                "+ additive_pool_kernel below its dispatch threshold)",
                                    "achieved": (f_fl / (f_ms * 1e-3) / 1e12) if f_ms > 0 else 0.0, "peak": FP32_MFMA_PEAK_TFLOPS,
                                    "unit": "TFLOP/s", "frac": (f_fl / (f_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS) if f_ms > 0 else 0.0,
                                    "launches_timed": f_n, "avg_launch_ms": f_ms / max(f_n, 1), "traffic": None},
                          parity_max_rel_err_vs_cpu=err)
+        tpath = os.path.join(ROOT, "profiles", "r04_traffic.json")
+        if name == "standard" and os.path.exists(tpath):  # counter traffic of the history tower's launch (committed PMC summary)
+            tj = json.load(open(tpath)).get("standard_fc1")
+            if tj:
+                out[name]["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
+                out[name]["roofline"]["traffic_source"] = {"file": "profiles/r04_traffic.json", "launch": tj.get("launch"),
+                                                            "alg_bytes": tj.get("algorithmic_bytes_per_launch"), "note": tj.get("note")}
         if name == "standard":  # the same forward without the masked token rows (device-compacted encoder)
             model.news_encoder.unpadded = True
             try:
@@ -764,7 +772,7 @@ def gather_roofline(device, n_news=16384, n=512 * 55, reps=5):
         del x
     out["achieved"], out["frac"] = out["uniform"]["achieved"], out["uniform"]["frac"]
     out["traffic"] = None
-    for tname in ("r03_traffic.json", "r02_traffic.json"):
+    for tname in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
@@ -1057,7 +1065,7 @@ def main():
         # bytes of THAT launch (`traffic_launch`), not next to the mean over this run's mixed launches; null when the file
         # does not say which launch it measured.
         traffic, traffic_source = None, None
-        for tname in ("r03_traffic.json", "r02_traffic.json"):
+        for tname in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
