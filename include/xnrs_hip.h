@@ -67,7 +67,8 @@ typedef struct {
 } xnrs_mha_params;
 
 /* layers.AdditiveAttention parameters (layers.py:42-45): fc1 Linear(D,A), fc2 Linear(A,1).
- * w1_folded / b1_folded (optional, inference entry points only; ABI version 3): fc1 folded behind the out-projection of
+ * w1_folded / b1_folded (optional; ABI version 3; the training entry points take them too since round 4 -- the backward
+ * call must then be given the same pair as its forward): fc1 folded behind the out-projection of
  * the attention stage passed IN THE SAME CALL -- W1.Wo [A,D] and W1.bo + b1 [A], as xnrs_fold_weights computes them
  * (DESIGN.md section 4.6).  The library keeps no state between calls, so without them every call rebuilds the pair
  * (three short launches, ~20 us); a caller that encodes with the same weights again and again computes them once

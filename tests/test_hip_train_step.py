@@ -336,3 +336,75 @@ def test_side_lane_of_the_backward_is_bitwise_neutral(model_name, monkeypatch):
         assert torch.equal(l0, l2)
         for k in g0:
             assert torch.equal(g0[k], g2[k]), k
+
+
+def test_folded_pair_is_computed_once_per_tower_and_weight_version(monkeypatch):
+    """autograd._train_fold: the W1.Wo / W1.bo + b1 pair of a training forward comes from a per-(tower, weight version) cache
+    and is handed to the forward and its backward (xnrs_additive_params.w1_folded): two optimizer steps with the cache equal
+    the same two steps with every call folding for itself, bit for bit, and the cache really was hit."""
+    from xnrs_amd import autograd as AG
+    c = dict(model="NRMS", B=8, H=12, C=3, S=50, D=64, h=4, E=32, bias=True, seed=4808, min_len=3)
+    monkeypatch.setattr(AG, "LIVE_ROWS_MIN", 1)
+    batch = synth.batch_to(cases.model_batch(c), DEV)
+    labels = torch.tensor([0, 1, 0, 2, 1, 0, 2, 2], device=DEV)
+
+    def two_steps(cache):
+        monkeypatch.setattr(AG, "FOLD_TRAIN_CACHE", cache)
+        AG._TRAIN_FOLDS.clear()
+        model = _nrms(c, 0.1)
+        opt = torch.optim.SGD(model.parameters(), lr=0.05)
+        out = []
+        for it in range(2):
+            loss, grads = _step(model, batch, labels, seed=77 + it)
+            opt.step()
+            out.append((loss, grads))
+        return out, {k: v.detach().clone() for k, v in model.state_dict().items()}
+    real = AG._train_fold
+    calls = {"n": 0, "miss": 0}
+
+    def spy(*a):
+        before = len(AG._TRAIN_FOLDS)
+        r = real(*a)
+        if r is not None:
+            calls["n"] += 1
+            calls["miss"] += int(len(AG._TRAIN_FOLDS) != before)
+        return r
+    monkeypatch.setattr(AG, "_train_fold", spy)
+    with_cache, sd1 = two_steps(True)
+    assert calls["n"] == 10 and calls["miss"] == 4, calls   # 5 tower calls per step, 2 towers: 2 folds per step instead of 5
+    without, sd0 = two_steps(False)
+    for (l1, g1), (l0, g0) in zip(with_cache, without):
+        assert torch.equal(l1, l0) and g1.keys() == g0.keys()
+        for k in g0:
+            assert torch.equal(g1[k], g0[k]), k
+    for k in sd0:
+        assert torch.equal(sd1[k], sd0[k]), k
+
+
+@pytest.mark.parametrize("model_name", ["NRMS", "standard"])
+def test_shared_parameter_gradients_are_summed_by_the_last_node(model_name, monkeypatch):
+    """autograd._sum_with_group: the calls of a tower that are not its last in a backward pass keep their parameter gradients
+    back and the last one adds them with one multi-tensor launch per kept set -- the gradients autograd's pairwise adds give,
+    up to the order of the additions (fp32 rounding), and the input gradient / loss bit for bit."""
+    from xnrs_amd import autograd as AG
+    c = dict(model=model_name, B=8, H=12, C=3, S=50, D=64, h=4, E=32, bias=True, seed=4909, min_len=3)
+    monkeypatch.setattr(AG, "LIVE_ROWS_MIN", 1)
+    model = _nrms(c, 0.1)
+    batch = synth.batch_to(cases.model_batch(c), DEV)
+    labels = torch.tensor([0, 1, 0, 2, 1, 0, 2, 2], device=DEV)
+    monkeypatch.setattr(AG, "SUM_SHARED_GRADS", False)
+    l0, g0 = _step(model, batch, labels)
+    monkeypatch.setattr(AG, "SUM_SHARED_GRADS", True)
+    kept = []
+    real = AG._sum_with_group
+
+    def spy(ctx, grads):
+        out = real(ctx, grads)
+        kept.append(all(t is None for t in out) and any(t is not None for t in grads))
+        return out
+    monkeypatch.setattr(AG, "_sum_with_group", spy)
+    l1, g1 = _step(model, batch, labels)
+    assert any(kept) and not all(kept)       # some node kept its set back, some node delivered
+    assert torch.equal(l0, l1)
+    _close(g1, g0, 2e-6)
+    assert all(not g.kept for g in AG._PARAM_GROUPS.values())  # nothing is left behind after a pass

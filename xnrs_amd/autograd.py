@@ -183,6 +183,114 @@ def _qkv_key(cfg, x, m, ids, params):
             _ident(ids), tuple(_ident(p) for p in params[:6]))  # (_att_tensors order: wq, bq, wk, bk, wv, bv, wo, bo)
 
 
+#: A tower's parameters are shared by every call of the tower (the news tower of a grad step is called for the candidates, the
+#: history and the history again: training.py:406,409), and autograd adds the calls' parameter gradients pairwise as they
+#: arrive -- one elementwise launch per parameter and extra call, 38 per NRMS step.  Here the calls that are NOT the last of
+#: their tower in a backward pass keep their parameter gradients back (they return None for them) and the last one -- the
+#: engine says which nodes are still to run: torch._C._will_engine_execute_node -- adds the kept sets to its own with ONE
+#: multi-tensor launch each (torch._foreach_add_) and returns the sums.  The same gradients up to the order of the additions;
+#: a hook on a parameter sees the sum once instead of each contribution.  XNRS_SUM_SHARED_GRADS=0: off.
+SUM_SHARED_GRADS = os.environ.get("XNRS_SUM_SHARED_GRADS", "1") != "0"
+_PARAM_GROUPS = {}
+
+
+class _ParamGroup:
+    """The live forward nodes of one tower (= one tuple of parameter tensors) and, during a backward pass, the gradient sets
+    its earlier nodes kept back."""
+    __slots__ = ("nodes", "kept", "task", "ran")
+
+    def __init__(self):
+        self.nodes, self.kept, self.task, self.ran = [], [], -1, {}
+
+
+def _join_group(ctx, params):
+    import weakref
+    if not SUM_SHARED_GRADS:
+        return None
+    key = tuple(None if p is None else id(p) for p in params)
+    if len(_PARAM_GROUPS) > 64:
+        for k in [k for k, g in _PARAM_GROUPS.items() if not any(r() is not None for r in g.nodes)]:
+            del _PARAM_GROUPS[k]
+    g = _PARAM_GROUPS.get(key)
+    if g is None:
+        g = _PARAM_GROUPS[key] = _ParamGroup()
+    g.nodes = [r for r in g.nodes if r() is not None]
+    g.nodes.append(weakref.ref(ctx))
+    return g
+
+
+def _sum_with_group(ctx, grads):
+    """Keep this node's parameter gradients back if another node of its tower is still to run in this pass; otherwise add what
+    the earlier nodes kept.  -> the list to return to autograd."""
+    g = getattr(ctx, "pgroup", None)
+    task = torch._C._current_graph_task_id()
+    if g is None or task == -1:
+        return grads
+    if g.task != task:  # (sets left by a pass that was abandoned are dropped)
+        g.kept, g.task = [], task
+    g.ran = {k: v for k, v in g.ran.items() if v == task}
+    g.ran[id(ctx)] = task
+    pending = False
+    for r in g.nodes:
+        n = r()
+        if n is None or n is ctx or g.ran.get(id(n)) == task:
+            continue
+        try:
+            if torch._C._will_engine_execute_node(n):
+                pending = True
+                break
+        except RuntimeError:
+            pass
+    if pending:
+        if any(t is not None for t in grads):
+            g.kept.append(grads)
+        return [None] * len(grads)
+    for kept in g.kept:
+        a, b = [], []
+        for j, t in enumerate(kept):
+            if t is None:
+                continue
+            if grads[j] is None:
+                grads[j] = t          # only an earlier node computed this one (a deferring node leaves its six to the merging one)
+            else:
+                a.append(grads[j])
+                b.append(t)
+        if a:
+            torch._foreach_add_(a, b)
+    g.kept = []
+    return grads
+
+
+#: The folded fc1 pair (W1.Wo, W1.bo + b1: DESIGN.md section 4.6) of a training forward is the same for every call with the
+#: same weights: a grad step calls the news tower three times and the user tower twice, so it is computed once per tower and
+#: weight version (xnrs_fold_weights; the same routine the in-call fold runs: the same bits) and handed to the forward AND
+#: its backward through xnrs_additive_params.w1_folded.  Keyed like every cache here on tensor identity + version counter +
+#: stream / capture status.  XNRS_FOLD_TRAIN_CACHE=0: every call folds for itself (three short launches).
+FOLD_TRAIN_CACHE = os.environ.get("XNRS_FOLD_TRAIN_CACHE", "1") != "0"
+_TRAIN_FOLDS = {}
+
+
+def _train_fold(l, cfg, params, ap, pp, dev):
+    """-> (w1f, b1f) tensors or None when this call does not fold (no attention + additive pair, fold switched off)."""
+    if not FOLD_TRAIN_CACHE or cfg.n_heads <= 0 or cfg.pool_kind != hip.POOL_ADDITIVE or not l.xnrs_train_fold_enabled():
+        return None
+    src = (params[6], params[7], params[8], params[9])  # out.weight, out.bias, fc1.weight, fc1.bias
+    key = (_where(dev), dev.index, cfg.D, cfg.A) + tuple(None if t is None else (id(t),) + _ident(t) for t in src)
+    hit = _TRAIN_FOLDS.get(key)
+    if hit is not None:
+        return hit
+    if len(_TRAIN_FOLDS) >= 8:  # (every optimizer step retires the entries of the step before)
+        _TRAIN_FOLDS.clear()
+    w1f = torch.empty((cfg.A, cfg.D), dtype=torch.float32, device=dev)
+    b1f = torch.empty((cfg.A,), dtype=torch.float32, device=dev)
+    nws = l.xnrs_fold_weights_workspace_bytes(cfg.D, cfg.A)
+    ws = hip.workspace(dev, nws)
+    hip.check(l.xnrs_fold_weights(C.byref(ap), C.byref(pp), cfg.D, hip.ptr(w1f), hip.ptr(b1f), hip.ptr(ws), nws, hip.stream_ptr(dev)),
+              "xnrs_fold_weights")
+    _TRAIN_FOLDS[key] = (w1f, b1f)
+    return w1f, b1f
+
+
 class _SeqEncode(torch.autograd.Function):
     """y = head(pool(att(x)))  (any stage optional) with saved activations for the HIP backward."""
 
@@ -198,6 +306,9 @@ class _SeqEncode(torch.autograd.Function):
         a = torch.empty((n, L), dtype=torch.float32, device=dev) if (cfg.want_a and cfg.pool_kind == hip.POOL_ADDITIVE) else None
         hm = torch.empty((n,), dtype=torch.float32, device=dev) if (pooled and m is not None) else None
         l = hip.lib()
+        ctx.fold_pair = _train_fold(l, cfg, params, ap, pp, dev)
+        if ctx.fold_pair is not None:
+            pp.w1_folded, pp.b1_folded = ctx.fold_pair[0].data_ptr(), ctx.fold_pair[1].data_ptr()
         nsaved = l.xnrs_seq_encoder_saved_bytes(n, L, D, cfg.A, Eo, cfg.n_heads, cfg.pool_kind, int(cfg.has_head))
         saved = torch.empty(max(nsaved, 1), dtype=torch.uint8, device=dev)
         # Nothing that flows through a masked token row reaches the output or a gradient (its pooling weight is
@@ -255,6 +366,7 @@ class _SeqEncode(torch.autograd.Function):
             for k in [k for k, v in _QKV_IMAGES.items() if v[0]() is None]:
                 del _QKV_IMAGES[k]
             _QKV_IMAGES[key] = (weakref.ref(saved), ctx.row_lists, weakref.ref(ctx))
+        ctx.pgroup = _join_group(ctx, params)
         ctx.fold = l.xnrs_train_fold_enabled()  # the saved blob is laid out by this decision (include/xnrs_hip.h)
         ctx.cfg = cfg
         ctx.nsaved = nsaved
@@ -276,6 +388,8 @@ class _SeqEncode(torch.autograd.Function):
         n, L, D = cfg.n_seq, cfg.L, cfg.D
         Eo = cfg.E if cfg.has_head else D
         ap, pp, hp, keep = _param_structs(cfg, params)
+        if getattr(ctx, "fold_pair", None) is not None:  # the pair the forward was given (the saved blob holds no copy then)
+            pp.w1_folded, pp.b1_folded = ctx.fold_pair[0].data_ptr(), ctx.fold_pair[1].data_ptr()
         dy = hip.dev_f32(dy, "grad output")
         need = ctx.needs_input_grad  # (cfg, x, m, ids, *params)
         want_dx = need[1]
@@ -334,7 +448,7 @@ class _SeqEncode(torch.autograd.Function):
                                               _ref(hp), hip.ptr(saved), ctx.nsaved, hip.ptr(dy), hip.ptr(dx), _ref(ga),
                                               _ref(gp), _ref(gh), _ref(lists), hip.ptr(ws), nws,
                                               hip.stream_ptr(dev)), "xnrs_seq_encoder_bwd_rows")
-        return (None, dx, None, None, *grads)
+        return (None, dx, None, None, *_sum_with_group(ctx, grads))
 
 
 def _host_lists(cfg, m, ids, dev):

@@ -462,7 +462,8 @@ int32_t seq_encode(const float* x, const float* m, const int32_t* ids, int64_t n
   const float* fc1_w = additive ? pool->w1 : nullptr;
   const float* fc1_b = additive ? pool->b1 : nullptr;
   if (fold) {
-    if (!train && pool->w1_folded) {  // the caller's copy of the folded pair (xnrs_fold_weights): nothing to rebuild
+    if (pool->w1_folded) {  // the caller's copy of the folded pair (xnrs_fold_weights): nothing to rebuild (training: the backward
+                            // call is then given the same pair -- the saved blob's copy stays unwritten)
       fc1_w = pool->w1_folded;
       fc1_b = att->bo ? pool->b1_folded : pool->b1;
       if (att->bo && !pool->b1_folded) return XNRS_EINVAL;
@@ -1711,13 +1712,14 @@ int32_t xnrs_seq_encoder_bwd_rows(const float* x, const float* m, const int32_t*
       //   dW' = dpre^T O, db' = sum dpre:  dW1 = dW' Wo^T + db' (x) bo,  db1 = db'
       //   dWo = dp^T po + W1^T dW',  dbo = sum_n s_n dp_n + W1^T db'      (one stacked product / column sum each)
       // The three rows x D x D products of the per-token order (forward out-projection, dO = dY Wo, dWo = dY^T O) are gone.
-      const float* wf = reinterpret_cast<const float*>(sv + sp.off_fw);
+      const float* wf = pool->w1_folded ? pool->w1_folded : reinterpret_cast<const float*>(sv + sp.off_fw);  // (as the forward was given)
       const float* pob = reinterpret_cast<const float*>(sv + sp.off_po);
       const float* asum = reinterpret_cast<const float*>(sv + sp.off_as);
       float* gvec = reinterpret_cast<float*>(w + bp.off_g);
       float* cvec = reinterpret_cast<float*>(w + bp.off_c);
       float* dwf = reinterpret_cast<float*>(w + bp.off_dwf);
-      float* dbf = reinterpret_cast<float*>(w + bp.off_dbf);
+      // db' IS db1 (see the algebra above): produced in place when the caller wants it (a device copy per call before)
+      float* dbf = (g_pool && g_pool->b1) ? g_pool->b1 : reinterpret_cast<float*>(w + bp.off_dbf);
       XNRS_TRY(gemm_dx(dpool, D, att->wo, gvec, D, n_seq, D, D, nullptr, 0, 0, 0, stream, wt));
       if (att->bo)
         XNRS_TRY(launch_gemm_f32(gemm1(dpool, nullptr, 0, D, att->bo, nullptr, cvec, 1, n_seq, 1, D, XNRS_ACT_NONE), stream));
@@ -1747,8 +1749,6 @@ int32_t xnrs_seq_encoder_bwd_rows(const float* x, const float* m, const int32_t*
         XNRS_TRY(launch_gemm_f32(gemm1(dwf, nullptr, 0, D, att->wo, nullptr, g_pool->w1, D, A, D, D, XNRS_ACT_NONE), sw));
         if (att->bo) XNRS_TRY(launch_add_rowscaled_bias(g_pool->w1, D, dbf, att->bo, A, D, sw));
       }
-      if (g_pool && g_pool->b1)
-        XNRS_TRY(hipMemcpyAsync(g_pool->b1, dbf, (size_t)A * sizeof(float), hipMemcpyDeviceToDevice, sw));
       // dWo = dp^T po + W1^T dW' as two products (the second accumulates), dbo = sum_n s_n dp_n + sum_a db'_a W1[a,:] as ONE
       // column sum over the two row blocks (round 3 staged [dp; W1] and [po; dW'] with six device copies per call)
       if (g_att && g_att->wo) {

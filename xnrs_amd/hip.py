@@ -440,6 +440,7 @@ def invalidate_fold_cache():
     from . import autograd
     autograd._QKV_IMAGES.clear()
     autograd._OUTPUTS.clear()
+    autograd._TRAIN_FOLDS.clear()
 
 
 def folded_fc1(att, pool):
