@@ -375,11 +375,14 @@ class _SeqEncode(torch.autograd.Function):
         ctx.param_none = [p is None for p in params]
         outs = [y, a if a is not None else y.new_empty(0), hm if hm is not None else y.new_empty(0)]
         ctx.mark_non_differentiable(outs[1], outs[2])
+        ctx.set_materialize_grads(False)  # (the two side outputs never carry a gradient: no zero tensors are made for them)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, dy, _da, _dhm):
         _OUTPUTS.pop(getattr(ctx, "okey", None), None)  # the graph is being consumed: its outputs are no longer shareable
+        if dy is None:  # (nothing flows into the only differentiable output)
+            return (None,) * (4 + ctx.n_params)
         cfg = ctx.cfg
         x, m, ids, saved, *ptensors = ctx.saved_tensors
         it = iter(ptensors)

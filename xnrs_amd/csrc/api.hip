@@ -1388,7 +1388,7 @@ BwdPlan make_bwd_plan(int64_t n_seq, int L, int D, int A, int E, int n_heads, bo
   int maxn = 3 * D;
   if (A > maxn) maxn = A;
   if (E > maxn) maxn = E;
-  p.off_colsum = take(colsum_workspace_bytes(maxn));
+  p.off_colsum = take(colsum_workspace_bytes(maxn + 1));  // (+ 1: launch_colsum_wsum's column of ones)
   // one transposed weight at a time (gemm_dx): the largest of D x D, A x D, E x D, E x E
   size_t wdim = (size_t)D;
   if ((size_t)A > wdim) wdim = (size_t)A;
@@ -1716,13 +1716,11 @@ int32_t xnrs_seq_encoder_bwd_rows(const float* x, const float* m, const int32_t*
       const float* pob = reinterpret_cast<const float*>(sv + sp.off_po);
       const float* asum = reinterpret_cast<const float*>(sv + sp.off_as);
       float* gvec = reinterpret_cast<float*>(w + bp.off_g);
-      float* cvec = reinterpret_cast<float*>(w + bp.off_c);
       float* dwf = reinterpret_cast<float*>(w + bp.off_dwf);
       // db' IS db1 (see the algebra above): produced in place when the caller wants it (a device copy per call before)
       float* dbf = (g_pool && g_pool->b1) ? g_pool->b1 : reinterpret_cast<float*>(w + bp.off_dbf);
       XNRS_TRY(gemm_dx(dpool, D, att->wo, gvec, D, n_seq, D, D, nullptr, 0, 0, 0, stream, wt));
-      if (att->bo)
-        XNRS_TRY(launch_gemm_f32(gemm1(dpool, nullptr, 0, D, att->bo, nullptr, cvec, 1, n_seq, 1, D, XNRS_ACT_NONE), stream));
+
       AdditivePoolBwdArgs pa{};
       pa.dp = gvec;
       pa.x = o;
@@ -1734,7 +1732,8 @@ int32_t xnrs_seq_encoder_bwd_rows(const float* x, const float* m, const int32_t*
       pa.lddx = D;
       pa.dpre = dpre;
       pa.de = de;
-      pa.da_shift = att->bo ? cvec : nullptr;
+      pa.shift_u = att->bo ? dpool : nullptr;  // c_n = dp_n . bo, taken inside the kernel
+      pa.shift_v = att->bo;
       pa.n_seq = n_seq;
       pa.N = L;
       pa.D = D;
@@ -1742,12 +1741,17 @@ int32_t xnrs_seq_encoder_bwd_rows(const float* x, const float* m, const int32_t*
       XNRS_TRY(launch_additive_pool_bwd(pa, stream));
       sw = fk.after_main();  // dpool (dp), dpre, de
       XNRS_TRY(gemm_dx(dpre, A, wf, docat, D, rows, A, D, nullptr, 0, 0, /*accumulate*/ 1, stream, wt, lv, n_live, cnt_live));
-      if (g_pool && g_pool->w2) XNRS_TRY(launch_colsum(t, A, de, rows, A, g_pool->w2, csum, sw));
-      if (g_pool && g_pool->b2) XNRS_TRY(launch_colsum(de, 1, nullptr, rows, 1, g_pool->b2, csum, sw));
+      if (g_pool && g_pool->w2 && g_pool->b2) XNRS_TRY(launch_colsum_wsum(t, A, de, rows, A, g_pool->w2, g_pool->b2, csum, sw));
+      else if (g_pool && g_pool->w2) XNRS_TRY(launch_colsum(t, A, de, rows, A, g_pool->w2, csum, sw));
+      else if (g_pool && g_pool->b2) XNRS_TRY(launch_colsum(de, 1, nullptr, rows, 1, g_pool->b2, csum, sw));
       XNRS_TRY(gemm_dw(dpre, A, o, nullptr, 0, D, dwf, rows, A, D, slabs, sw, lv, lv, n_live, dbf, csum, cnt_live));
       if (g_pool && g_pool->w1) {
-        XNRS_TRY(launch_gemm_f32(gemm1(dwf, nullptr, 0, D, att->wo, nullptr, g_pool->w1, D, A, D, D, XNRS_ACT_NONE), sw));
-        if (att->bo) XNRS_TRY(launch_add_rowscaled_bias(g_pool->w1, D, dbf, att->bo, A, D, sw));
+        GemmArgs g1 = gemm1(dwf, nullptr, 0, D, att->wo, nullptr, g_pool->w1, D, A, D, D, XNRS_ACT_NONE);
+        if (att->bo) {  // + db' (x) bo in the epilogue: fmaf(db'[a], bo[d], acc), the bits of the separate pass it replaces
+          g1.rowscale = dbf;
+          g1.rowscale_vec = att->bo;
+        }
+        XNRS_TRY(launch_gemm_f32(g1, sw));
       }
       // dWo = dp^T po + W1^T dW' as two products (the second accumulates), dbo = sum_n s_n dp_n + sum_a db'_a W1[a,:] as ONE
       // column sum over the two row blocks (round 3 staged [dp; W1] and [po; dW'] with six device copies per call)
@@ -1782,8 +1786,9 @@ int32_t xnrs_seq_encoder_bwd_rows(const float* x, const float* m, const int32_t*
       pa.A = A;
       XNRS_TRY(launch_additive_pool_bwd(pa, stream));
       sw = fk.after_main();  // dpre, de
-      if (g_pool && g_pool->w2) XNRS_TRY(launch_colsum(t, A, de, rows, A, g_pool->w2, csum, sw));
-      if (g_pool && g_pool->b2) XNRS_TRY(launch_colsum(de, 1, nullptr, rows, 1, g_pool->b2, csum, sw));
+      if (g_pool && g_pool->w2 && g_pool->b2) XNRS_TRY(launch_colsum_wsum(t, A, de, rows, A, g_pool->w2, g_pool->b2, csum, sw));
+      else if (g_pool && g_pool->w2) XNRS_TRY(launch_colsum(t, A, de, rows, A, g_pool->w2, csum, sw));
+      else if (g_pool && g_pool->b2) XNRS_TRY(launch_colsum(de, 1, nullptr, rows, 1, g_pool->b2, csum, sw));
       if (g_pool && g_pool->w1 && live)  // rows of dpre through lv; rows of seq through lv (yatt) or lvx (x / table rows)
         XNRS_TRY(gemm_dw(dpre, A, seq, nullptr, 0, D, g_pool->w1, rows, A, D, slabs, sw, lv, att ? lv : lvx, n_live, g_pool->b1, csum, cnt_live));
       else if (g_pool && g_pool->w1)

@@ -472,6 +472,8 @@ struct AdditivePoolBwdArgs {
   float* dpre;       // [n_seq*N, A] gradient at the fc1 pre-activation
   float* de;         // [n_seq*N] gradient at the fc2 output (score)
   const float* da_shift;  // nullable [n_seq]: added to every da_i of the sequence (folded out-projection: dp . bo)
+  const float* shift_u;   // nullable pair: ... or that shift taken here as the dot product of row `seq` of shift_u [n_seq, D]
+  const float* shift_v;   // with shift_v [D] (one launch less than a GEMV in front of this kernel)
   int64_t n_seq;
   int32_t N, D, A;
 };
@@ -484,6 +486,10 @@ hipError_t launch_colsum(const float* X, int64_t ldx, const float* w, int64_t M,
 // the same over two row blocks stacked: out[n] = sum_m w[m] X[m][n] + sum_m w2[m] X2[m][n]  (M2 rows of pitch ldx2)
 hipError_t launch_colsum2(const float* X, int64_t ldx, const float* w, int64_t M, const float* X2, int64_t ldx2, const float* w2,
                           int64_t M2, int N, float* out, float* partial, hipStream_t stream);
+// ... and the sum of the row weights themselves beside it: out[n] = sum_r w[r] X[r][n], wsum_out[0] = sum_r w[r]
+// (partial sized for N + 1 columns)
+hipError_t launch_colsum_wsum(const float* X, int64_t ldx, const float* w, int64_t M, int N, float* out, float* wsum_out,
+                              float* partial, hipStream_t stream);
 // out[n] = sum_s partial[s][n] in a fixed order (second stage of launch_colsum; also reduces GemmArgs::colsum)
 hipError_t launch_colsum_final(const float* partial, int nsplit, int N, float* out, hipStream_t stream);
 hipError_t launch_dot_scoring_bwd(const float* u, const float* c, const float* dr, float* du, float* dc, int64_t B, int32_t C,

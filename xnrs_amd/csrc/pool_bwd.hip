@@ -34,8 +34,17 @@ __global__ __launch_bounds__(256) void additive_pool_bwd_kernel(AdditivePoolBwdA
   const int64_t srcx = a.x_gather_ids ? (int64_t)a.x_gather_ids[seq] : seq;
   const float* x = a.x + srcx * N * a.ldx;
   const float* dp = a.dp + seq * D;
-  const float shift = a.da_shift ? a.da_shift[seq] : 0.f;
+  float shift = a.da_shift ? a.da_shift[seq] : 0.f;
   for (int i = tid; i < N; i += 256) s_a[i] = a.a[seq * N + i];
+  if (a.shift_u) {  // (kernel argument: uniform) shift = <shift_u[seq], shift_v>, summed in a fixed order
+    const float* u = a.shift_u + seq * D;
+    float p = 0.f;
+    for (int d = tid; d < D; d += 256) p = fmaf(u[d], a.shift_v[d], p);
+    p = wave_sum_b(p);
+    if (lane == 0) s_red[wave] = p;
+    __syncthreads();
+    shift = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  }
   __syncthreads();
   // rows with a_i == 0 (masked tokens: exp(e) * 0) contribute nothing -- de_i = a_i (...) = 0 whatever da_i is -- so their
   // value rows and tanh rows are not read at all (55 % of the rows of the benchmark batch), only their zeros written
@@ -171,18 +180,21 @@ hipError_t launch_mean_pool_bwd(const float* dy, const float* mask, const int32_
 constexpr int COLSUM_ROWS = 128;
 constexpr int COLSUM_MAX_SPLITS = 4096;
 
+// NX = N, or N + 1: one more column of ones -- its sum is the sum of the row weights themselves (the additive pooler's fc2
+// BIAS gradient sum_r de_r beside its weight gradient sum_r de_r t_r: one pass over de instead of two launch pairs)
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* X, int64_t ldx, const float* w, int64_t M, int N,
                                                               int64_t rows_per, float* partial, const float* X2, int64_t ldx2,
-                                                              const float* w2, int64_t M1) {
+                                                              const float* w2, int64_t M1, int NX) {
   const int n = blockIdx.x * 256 + threadIdx.x;
   const int sp = blockIdx.y;
   const int64_t r0 = sp * rows_per;
   const int64_t r1 = (r0 + rows_per < M) ? r0 + rows_per : M;
-  if (n >= N) return;
+  if (n >= NX) return;
+  const bool ones = n >= N;
   // rows >= M1 come from the second block (launch_colsum2; M1 = M without one)
   auto term = [&](int64_t r, float acc) {
     const bool second = r >= M1;
-    const float x = second ? X2[(r - M1) * ldx2 + n] : X[r * ldx + n];
+    const float x = ones ? 1.f : (second ? X2[(r - M1) * ldx2 + n] : X[r * ldx + n]);
     const float* ww = second ? w2 : w;
     return ww ? fmaf(ww[second ? r - M1 : r], x, acc) : acc + x;
   };
@@ -196,35 +208,42 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* X, int
   }
   for (int e = 0; r < r1; ++r, ++e) a4[e] = term(r, a4[e]);
   const float acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-  partial[(int64_t)sp * N + n] = acc;
+  partial[(int64_t)sp * NX + n] = acc;
 }
 
 // one wave per column: lane l adds partials l, l+64, ... in order, then a fixed shuffle tree
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, int nsplit, int N, float* out) {
+// (out_last: column N - 1 goes there instead -- the weight-sum column of launch_colsum_wsum)
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, int nsplit, int N, float* out, float* out_last) {
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
   const int lane = threadIdx.x & 63;
   float acc = 0.f;
   for (int s = lane; s < nsplit; s += 64) acc += partial[(int64_t)s * N + n];
   acc = wave_sum_b(acc);
-  if (lane == 0) out[n] = acc;
+  if (lane == 0) {
+    if (out_last && n == N - 1) out_last[0] = acc;
+    else out[n] = acc;
+  }
 }
 
 hipError_t launch_colsum_final(const float* partial, int nsplit, int N, float* out, hipStream_t stream) {
   if (N <= 0) return hipSuccess;
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, partial, nsplit, N, out);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, partial, nsplit, N, out,
+                     (float*)nullptr);
   return hipGetLastError();
 }
 
 size_t colsum_workspace_bytes(int N) { return (size_t)COLSUM_MAX_SPLITS * (size_t)N * sizeof(float); }
 
-hipError_t launch_colsum2(const float* X, int64_t ldx, const float* w, int64_t M1, const float* X2, int64_t ldx2, const float* w2,
-                          int64_t M2, int N, float* out, float* partial, hipStream_t stream) {
+static hipError_t colsum_impl(const float* X, int64_t ldx, const float* w, int64_t M1, const float* X2, int64_t ldx2, const float* w2,
+                              int64_t M2, int N, float* out, float* wsum_out, float* partial, hipStream_t stream) {
   if (N <= 0) return hipSuccess;
+  if (wsum_out && (!w || X2)) return hipErrorInvalidValue;
+  const int NX = N + (wsum_out ? 1 : 0);
   const int64_t M = M1 + (X2 ? M2 : 0);
   // rows per slice: enough slices to fill the chip (~1024 workgroups with the column blocks), 8 .. COLSUM_ROWS rows each --
   // a 320-row reduction used to run as three workgroups walking 128 rows serially (31 us for 0.3 MB)
-  const int64_t col_blocks = (N + 255) / 256;
+  const int64_t col_blocks = (NX + 255) / 256;
   const int64_t want = col_blocks >= 1024 ? 1 : 1024 / col_blocks;
   int64_t rows_per = (M + want - 1) / want;
   if (rows_per < 8) rows_per = 8;
@@ -232,12 +251,23 @@ hipError_t launch_colsum2(const float* X, int64_t ldx, const float* w, int64_t M
   if ((M + rows_per - 1) / rows_per > COLSUM_MAX_SPLITS) rows_per = (M + COLSUM_MAX_SPLITS - 1) / COLSUM_MAX_SPLITS;
   int nsplit = (int)((M + rows_per - 1) / rows_per);
   if (nsplit < 1) nsplit = 1;
-  const dim3 g1((unsigned)((N + 255) / 256), (unsigned)nsplit);
-  hipLaunchKernelGGL(colsum_partial_kernel, g1, dim3(256), 0, stream, X, ldx, w, M, N, rows_per, partial, X2, ldx2, w2, M1);
+  const dim3 g1((unsigned)((NX + 255) / 256), (unsigned)nsplit);
+  hipLaunchKernelGGL(colsum_partial_kernel, g1, dim3(256), 0, stream, X, ldx, w, M, N, rows_per, partial, X2, ldx2, w2, M1, NX);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, partial, nsplit, N, out);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((NX + 3) / 4)), dim3(256), 0, stream, partial, nsplit, NX, out, wsum_out);
   return hipGetLastError();
+}
+
+hipError_t launch_colsum2(const float* X, int64_t ldx, const float* w, int64_t M1, const float* X2, int64_t ldx2, const float* w2,
+                          int64_t M2, int N, float* out, float* partial, hipStream_t stream) {
+  return colsum_impl(X, ldx, w, M1, X2, ldx2, w2, M2, N, out, nullptr, partial, stream);
+}
+
+// out[n] = sum_r w[r] X[r][n] AND wsum_out[0] = sum_r w[r] in one pass (partial: colsum_workspace_bytes(N + 1))
+hipError_t launch_colsum_wsum(const float* X, int64_t ldx, const float* w, int64_t M, int N, float* out, float* wsum_out,
+                              float* partial, hipStream_t stream) {
+  return colsum_impl(X, ldx, w, M, nullptr, 0, nullptr, 0, N, out, wsum_out, partial, stream);
 }
 
 hipError_t launch_colsum(const float* X, int64_t ldx, const float* w, int64_t M, int N, float* out, float* partial,
