@@ -701,3 +701,35 @@ def test_second_history_encode_reuses_the_first_projection():
     assert AG.STATS["shared_qkv_forwards"] == before
     model.news_encoder.dropout.p = 0.0
     AG.SHARE_OUTPUTS = True
+
+
+@pytest.mark.parametrize("n_rows,K,shape", [(20, 100, (64, 25)), (301, 100, (7, 3)), (5, 36, (1, 1)), (33, 600, (9, 11)), (20, 512, (64, 30))])
+def test_embedding_table_gradient_vs_index_add(n_rows, K, shape):
+    """nn.Embedding backward behind the fused embedding + Linear op (naml.py:82-86): the ballot-scan kernel (K <= 512: four
+    waves over the quarters of the id list) and the wide fallback against an fp64 index_add of the same row gradients; list
+    lengths that are no multiple of 4 or 64, rows nobody refers to (zero gradient), one-element lists."""
+    from xnrs_amd import ops
+    g = torch.Generator().manual_seed(1000 + n_rows + K)
+    emb = torch.nn.Embedding(n_rows, K)
+    fc = torch.nn.Linear(K, 24)
+    with torch.no_grad():
+        emb.weight.copy_(torch.randn(n_rows, K, generator=g))
+        fc.weight.copy_(torch.randn(24, K, generator=g) / K ** 0.5)
+        fc.bias.copy_(torch.randn(24, generator=g))
+    idx = torch.randint(0, n_rows, shape, generator=g)
+    if n_rows > 8:
+        idx[idx == 3] = 4            # row 3 is never referred to
+    dy = torch.randn(*shape, 24, generator=g)
+    w64, t64, b64 = fc.weight.detach().double().clone(), emb.weight.detach().double().clone(), fc.bias.detach().double().clone()
+    emb_d, fc_d = emb.to(DEV), fc.to(DEV)  # (nn.Module.to moves in place: the fp64 copies above stay on the host)
+    y = ops.embedding_linear(idx.to(DEV), emb_d, fc_d)
+    y.backward(dy.to(DEV))
+    # reference in fp64
+    d_rows = dy.double().reshape(-1, 24) @ w64
+    ref = torch.zeros(n_rows, K, dtype=torch.float64).index_add_(0, idx.reshape(-1), d_rows)
+    got = emb_d.weight.grad.cpu().double()
+    scale = max(ref.abs().max().item(), 1e-6)
+    assert (got - ref).abs().max().item() <= 5e-6 * scale * max(1.0, (idx.numel() / n_rows) ** 0.5)
+    if n_rows > 8:
+        assert torch.equal(got[3], torch.zeros(K, dtype=torch.float64))
+    assert torch.allclose(y.detach().cpu().double(), t64[idx] @ w64.t() + b64, rtol=1e-5, atol=1e-5)

@@ -354,10 +354,48 @@ hipError_t launch_dot_scoring_bwd(const float* u, const float* c, const float* d
 namespace xnrs {
 
 // d_table[r, :] = sum over m with ids[m] == r of d_rows[m, :]   (nn.Embedding backward for the small
-// category tables of NAML, naml.py:82-86).  One block per table row scans the ids in order: deterministic,
-// no atomics; O(n_rows * M) index compares is negligible for tables of tens to hundreds of rows.
-__global__ __launch_bounds__(64) void embedding_grad_kernel(const float* d_rows, const int32_t* ids, int64_t M, int K,
-                                                             float* d_table) {
+// category tables of NAML, naml.py:82-86).  One workgroup per table row: its four waves take the four quarters of the id
+// list, each reads 64 ids at a time, finds its row's occurrences with a ballot and adds their gradient rows (lanes =
+// features) in list order; the four partial rows are added in wave order.  Deterministic, no atomics.  (Round 4: the first
+// version -- one wave walking the ids one by one, once per 64 features -- took 80-90 us per table at M = 1 600: 0.5 of the
+// 3.2 ms of the NAML grad step.)
+constexpr int EMB_MAX_PASSES = 8;  // features per lane: K <= 512 on the fast kernel
+
+__global__ __launch_bounds__(256) void embedding_grad_kernel(const float* __restrict__ d_rows, const int32_t* __restrict__ ids,
+                                                              int64_t M, int K, float* __restrict__ d_table) {
+  __shared__ float s_part[4][64 * EMB_MAX_PASSES];
+  const int r = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t per = (M + 3) / 4;
+  const int64_t m0 = wave * per, m1 = (m0 + per < M) ? m0 + per : M;
+  float acc[EMB_MAX_PASSES];
+#pragma unroll
+  for (int p = 0; p < EMB_MAX_PASSES; ++p) acc[p] = 0.f;
+  for (int64_t base = m0; base < m1; base += 64) {
+    const int64_t m = base + lane;
+    const bool hit = m < m1 && ids[m] == r;
+    unsigned long long mask = __ballot(hit);
+    while (mask) {  // (wave-uniform)
+      const int b = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const float* row = d_rows + (base + b) * K;
+#pragma unroll
+      for (int p = 0; p < EMB_MAX_PASSES; ++p) {
+        const int k = p * 64 + lane;
+        if (k < K) acc[p] += row[k];
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < EMB_MAX_PASSES; ++p) s_part[wave][p * 64 + lane] = acc[p];
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += 256)
+    d_table[(int64_t)r * K + k] = ((s_part[0][k] + s_part[1][k]) + s_part[2][k]) + s_part[3][k];
+}
+
+// any K: one wave per table row, the ids one by one
+__global__ __launch_bounds__(64) void embedding_grad_wide_kernel(const float* d_rows, const int32_t* ids, int64_t M, int K,
+                                                                  float* d_table) {
   const int r = blockIdx.x;
   for (int k0 = 0; k0 < K; k0 += 64) {
     const int k = k0 + threadIdx.x;
@@ -371,7 +409,10 @@ __global__ __launch_bounds__(64) void embedding_grad_kernel(const float* d_rows,
 hipError_t launch_embedding_grad(const float* d_rows, const int32_t* ids, int64_t M, int K, float* d_table, int n_rows,
                                  hipStream_t stream) {
   if (n_rows <= 0) return hipSuccess;
-  hipLaunchKernelGGL(embedding_grad_kernel, dim3((unsigned)n_rows), dim3(64), 0, stream, d_rows, ids, M, K, d_table);
+  if (K <= 64 * EMB_MAX_PASSES)
+    hipLaunchKernelGGL(embedding_grad_kernel, dim3((unsigned)n_rows), dim3(256), 0, stream, d_rows, ids, M, K, d_table);
+  else
+    hipLaunchKernelGGL(embedding_grad_wide_kernel, dim3((unsigned)n_rows), dim3(64), 0, stream, d_rows, ids, M, K, d_table);
   return hipGetLastError();
 }
 
