@@ -19,7 +19,7 @@ model, opt, batch, targets, labels, fn = bench.make_train_job(name, dev)
 for _ in range(3):
     fn()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     fn()
     torch.cuda.synchronize()
 ev = prof.events()
@@ -42,3 +42,18 @@ names = collections.Counter(k.name[:70] for k in kern)
 print("--- kernels by name")
 for n, c in names.most_common(80):
     print(f"{c:4d}  {n}")
+
+print("--- torch (non-xnrs) kernels by device time")
+tk = sorted([k for k in kern if "xnrs::" not in k.name], key=lambda k: -k.device_time_total if hasattr(k, "device_time_total") else 0)
+for k in tk[:12]:
+    print(f"{getattr(k, 'device_time_total', 0):8.1f} us  {k.name[:100]}")
+print("--- operators owning them (name, input shapes, device time of the op's kernels)")
+rows = []
+for e in ev:
+    if e.device_type != torch.autograd.DeviceType.CPU or not e.kernels or any(c.kernels for c in e.cpu_children):
+        continue
+    if any("xnrs::" in k.name for k in e.kernels):
+        continue
+    rows.append((sum(k.duration for k in e.kernels), e.name, str(e.input_shapes)[:120], [s for s in (e.stack or []) if "repo" in s][:2]))
+for r in sorted(rows, key=lambda r: -r[0])[:12]:
+    print(f"{r[0]:8.1f} us  {r[1]:28s} {r[2]}  {r[3]}")
