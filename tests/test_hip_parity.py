@@ -627,3 +627,44 @@ def test_attention_rows_of_masked_queries_are_not_computed_in_pooled_calls(pool)
     assert torch.equal(y1, y0) and torch.equal(hm1, hm0)
     yo, hmo = O.text_encoder(x, m, sd, h)
     H.assert_close(y1, yo, what="news vectors vs oracle")
+
+
+@pytest.mark.parametrize("name", ["NRMS", "standard"])
+def test_one_news_encoder_call_for_a_small_request_is_bitwise_the_two_calls(name):
+    """ParentRec._forward in inference: history and candidates of a small request go through ONE news-encoder call (a news
+    vector depends on its own rows only) -- scores and embeddings bit for bit those of the reference's two calls; the same for
+    the id path (one call over the ids of both sides)."""
+    from tests.golden import cases
+    from xnrs_amd import synth
+    from xnrs_amd.models import make_model
+
+    class Cfg(dict):
+        __getattr__ = dict.__getitem__
+    c = dict(model=name, B=3, H=7, C=4, S=20, D=64, h=4, E=32, bias=True, seed=6101, min_len=3)
+    model = make_model(Cfg(cases.model_cfg(c)))
+    model.load_state_dict(synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 6102))
+    model = model.eval().to(DEV)
+    batch = synth.batch_to(cases.model_batch(c), DEV)
+    hist = batch["user_features"]["history"]["title_emb"]
+    cand = batch["candidate_features"]["title_emb"]
+    with torch.no_grad():
+        assert model._one_news_call(hist, cand)
+        r1, u1, c1 = model._forward(hist, cand, return_embeddings=True)
+        model.ONE_CALL_MAX_BYTES = 0
+        try:
+            assert not model._one_news_call(hist, cand)
+            r0, u0, c0 = model._forward(hist, cand, return_embeddings=True)
+        finally:
+            del model.ONE_CALL_MAX_BYTES
+    assert torch.equal(r1, r0) and torch.equal(u1, u0) and torch.equal(c1, c0)
+    assert not model.train()._one_news_call(hist, cand)  # (training keeps the reference's call structure)
+    model.eval()
+    # id path: a table of the batch's own news, ids = their positions
+    B, H, C = c["B"], c["H"], c["C"]
+    tx = torch.cat([hist[0].reshape(B * H, c["S"], c["D"]), cand[0].reshape(B * C, c["S"], c["D"])])
+    tm = torch.cat([hist[1].reshape(B * H, c["S"]), cand[1].reshape(B * C, c["S"])])
+    hid = torch.arange(B * H, device=DEV, dtype=torch.int32).reshape(B, H)
+    cid = (B * H + torch.arange(B * C, device=DEV, dtype=torch.int32)).reshape(B, C)
+    with torch.no_grad():
+        ri = model.forward_ids(tx, tm, hid, cid)
+    assert torch.equal(ri, r0)
