@@ -117,7 +117,10 @@ def test_random_bi_encoder_gradients_match_oracle(seed):
     the `+ 1e-8` of layers.py:64 keeps the weights from being invariant to it.  Both sides therefore compare two fp32 sums of
     n = rows terms that cancel analytically; what is left on EITHER side is summation noise of order sqrt(n) * 2^-23 * |de|,
     and |de| is bounded through its sibling gradient d fc2.weight = sum_i de_i tanh(.)_i.  Bar for this key: the usual
-    2e-4 of the scale PLUS 4 sqrt(n) 2^-23 max|d fc2.weight| (one round-3 soak seed sat at 2.1e-4 of the scale without it)."""
+    2e-4 of the scale PLUS 4 sqrt(n) 2^-23 max|d fc2.weight| (one round-3 soak seed sat at 2.1e-4 of the scale without it)
+    PLUS 1e-6 of the largest gradient of the step: each de_i is itself the difference a_i da_i - a_i c of two products that
+    can be far larger than de_i (c = sum_j a_j da_j contains the whole shift of the scores), so the noise that survives the
+    cancellation is a few ulps of THOSE, on both sides (round-4 soak seed 354: 2.6e-7 of the largest gradient)."""
     c = _cfg(100 + seed)
     D, S, A, h = c["D"], min(c["S"], 64), c["A"], c["h"]
     Eo = c["E"] if c["head_news"] else D
@@ -174,7 +177,7 @@ def test_random_bi_encoder_gradients_match_oracle(seed):
             if k.startswith("news_encoder."):
                 rows += c["B"] * c["C"] * S  # the candidates go through the same tower
             gw = osd[k[:-len("bias")] + "weight"].grad.abs().max().item()
-            bar += 4.0 * (rows ** 0.5) * 2.0 ** -23 * gw / scale
+            bar += 4.0 * (rows ** 0.5) * 2.0 ** -23 * gw / scale + 1e-6 * gmax / scale
         assert e <= bar, f"{what}: {k}: {e:.3e} (bar {bar:.3e})"
         n += 1
     assert n >= 2
